@@ -1,0 +1,126 @@
+/*
+ * vr_backend.h — C-ABI of the MI355X integrator backend (libvr_backend.so).
+ *
+ * Drop-in boundary for the per-pixel integrator hot path of emiliano-luna/volume-renderer.
+ * Each entry point cites the reference interface it replaces; paths are relative to
+ * /root/reference/VolumeRenderer/RayTracer/.  Plain pointers and sizes only; every function
+ * returns VR_OK (0) or a negative VR_ERR_* (vr_types.h) and never throws or exits — the
+ * reference's own convention is exit()/throw (SceneLoader.cpp:90,213), which cannot cross a
+ * C boundary.  INTEGRATION.md shows the reference-side binding.
+ *
+ * A vr_backend is bound to one GPU and must be driven from one host thread at a time.
+ * Inputs handed to vr_backend_set_* are copied to HBM before the call returns.
+ */
+#ifndef VR_BACKEND_H
+#define VR_BACKEND_H
+
+#include "vr_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vr_backend vr_backend;
+
+/* Arithmetic mode of the integrator kernels. */
+enum {
+    /* Polynomial log/exp/sin/cos shared with the CPU oracle, one Philox stream per
+     * (pixel, sample, bounce), one density lookup per step: results are bit-identical to
+     * oracle/vr_oracle.c in VRO_MATH_SHARED + VRO_RNG_PHILOX mode.  The parity mode. */
+    VR_MODE_EXACT = 0,
+    /* Same algorithm and random streams, hardware transcendentals (v_log_f32, v_exp_f32,
+     * v_sin_f32, v_cos_f32) and empty-space stepping batched per zero-majorant cell: differs
+     * from EXACT only by rounding.  The production mode. */
+    VR_MODE_FAST = 1
+};
+
+/* ---- life cycle -------------------------------------------------------------------------
+ * Replaces: SceneLoader::initializeDevice / rtcReleaseDevice (SceneLoader.cpp:25-34,
+ * SceneRenderer.cpp:27-28) — the reference's only "device" object. */
+int  vr_backend_create(int hip_device_ordinal, vr_backend** out);
+void vr_backend_destroy(vr_backend* b);
+/* Message of the last failing call on this backend ("" if none).  b may be NULL: then the
+ * message of the last failing vr_backend_create of this thread. */
+const char* vr_backend_last_error(const vr_backend* b);
+
+/* ---- scene ------------------------------------------------------------------------------
+ * Replaces the SceneInfo members the integrators read (Utils/Types.h:129-146), filled by
+ * SceneLoader::initializeScene (SceneLoader.cpp:43-233). */
+
+/* densityGrid / temperatureGrid + densityExtrema + gridBoundingBox (Types.h:141-145;
+ * SceneLoader.cpp:207-230).  The voxels are re-laid out in HBM as 8x8x8 bricks and a
+ * per-brick majorant grid is built.  temperature may be NULL. */
+int vr_backend_set_density(vr_backend* b, const vr_grid_desc* density, const vr_grid_desc* temperature);
+
+/* Fills the density grid on the device with the synthetic cloud of BASELINE configs 2-4:
+ * n^3 voxels (n a multiple of 8), voxel size 1, bbox centred on the origin, Perlin fbm of
+ * Utils/PerlinNoiseSampler.cpp:46-68 under a radial smoothstep.  No reference counterpart
+ * (its fields come from .nvdb files that are absent from the checkout). */
+int vr_backend_generate_cloud(vr_backend* b, int n, float radius_voxels);
+
+/* Reads the bricked density back as a dense k-fastest array of dims[0]*dims[1]*dims[2]
+ * floats (for checks); dims/bbox_min may be NULL. */
+int vr_backend_read_density(vr_backend* b, float* voxels, uint64_t capacity_floats, int32_t dims[3], int32_t bbox_min[3]);
+int vr_backend_density_max(vr_backend* b, float* max_value);
+
+/* scene + primitives + materials[].dissolve (Types.h:130-133; SceneLoader.cpp:69-175).
+ * Builds the BVH that replaces rtcIntersect1 (Utils/EmbreeHelper.cpp:4-36). */
+int vr_backend_set_mesh(vr_backend* b, const vr_mesh_desc* mesh);
+
+/* ---- knobs without a reference counterpart ---------------------------------------------- */
+int vr_backend_set_mode(vr_backend* b, int vr_mode);          /* default VR_MODE_FAST */
+int vr_backend_set_seed(vr_backend* b, uint64_t philox_key);  /* default 0x5EED0001   */
+/* Cap on the per-sample staging buffer in HBM (bytes); samples are rendered in passes that
+ * fit.  Default 4 GiB. */
+int vr_backend_set_sample_buffer_bytes(vr_backend* b, uint64_t bytes);
+
+/* ---- the hot path -----------------------------------------------------------------------
+ * vr_backend_render_rows replaces BaseIntegrator::renderPartial(Vec3f* orig, Vec3f* pix,
+ * ThreadInfo*, const Options&, SceneInfo*) (integrators/BaseIntegrator.h:67, .cpp:287-325)
+ * including the virtual castRay it calls (BaseIntegrator.h:65) for the four integrators of
+ * vr_integrator_id: absolute rows [from_row, to_row) (ThreadInfo::fromHeight/toHeight, i.e.
+ * heightStartOffset already added), all columns [widthStartOffset, widthStartOffset+width);
+ * writes width*(to_row-from_row) RGB float triples, row-major, first row first, into
+ * caller-owned HOST memory (the reference's `Vec3f* pix`). */
+int vr_backend_render_rows(vr_backend* b, const vr_options_pod* o, int integrator,
+                           uint32_t from_row, uint32_t to_row, float* pix_rgb);
+
+/* Replaces BaseIntegrator::render (BaseIntegrator.h:69, .cpp:131-190) up to the end of its
+ * timed span (:192): the whole width x height framebuffer, before tonemap and save. */
+int vr_backend_render(vr_backend* b, const vr_options_pod* o, int integrator, float* framebuffer_rgb);
+
+/* The same work with the output left in HBM, for the multi-GPU tile scheduler (the
+ * reference's chunk queue, BaseIntegrator.cpp:253-285 + Utils/MultithreadingHelper.cpp:10-28,
+ * hands out row chunks; here rank r of N takes rows row_first + k*row_stride):
+ * renders rows heightStartOffset + row_first + k*row_stride, k = 0..row_count-1, into
+ * d_rgb = DEVICE pointer to row_count*width*3 floats.  Asynchronous on the backend's stream;
+ * vr_backend_synchronize waits for it. */
+int vr_backend_render_row_set_device(vr_backend* b, const vr_options_pod* o, int integrator,
+                                     uint32_t row_first, uint32_t row_stride, uint32_t row_count,
+                                     void* d_rgb);
+int vr_backend_synchronize(vr_backend* b);
+
+/* Counters of the last render call (vr_types.h) and the HIP-event time of its integrator
+ * kernel launches in milliseconds (sum over passes), measured on the backend's stream. */
+int vr_backend_last_stats(vr_backend* b, vr_render_stats* stats, float* kernel_ms, uint32_t* kernel_launches);
+
+/* ---- post-process -----------------------------------------------------------------------
+ * Replaces the max-white scan + extended Reinhard of BaseIntegrator::render
+ * (BaseIntegrator.cpp:199-220) on a DEVICE buffer of npixels RGB triples, in place.
+ * max_white_in < 0: compute the maximum from the buffer (single GPU); otherwise use the
+ * given global maximum (multi-GPU: all-reduce MAX the per-rank maxima first).
+ * max_white_out may be NULL. */
+int vr_backend_tonemap_device(vr_backend* b, void* d_rgb, uint64_t npixels, float max_white_in, float* max_white_out);
+int vr_backend_max_channel_device(vr_backend* b, const void* d_rgb, uint64_t npixels, float* max_out);
+/* Replaces the pixel loop of BaseIntegrator::saveFile (BaseIntegrator.cpp:19-25): clamp to
+ * [0,1], *255 truncated; out = top-down RGB8 (the reference's flip puts framebuffer row 0 at
+ * the top of the PNG).  Host buffers. */
+int vr_rgb_to_u8(const float* rgb, uint32_t width, uint32_t height, uint8_t* out_rgb8);
+
+/* sizeof() of the boundary structs as compiled, for binding self-checks */
+void vr_abi_sizes(uint32_t out[4]); /* options, grid_desc, mesh_desc, render_stats */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VR_BACKEND_H */

@@ -1,0 +1,902 @@
+// vr_backend.hip — C-ABI implementation (include/vr_backend.h) over the HIP kernels.
+//
+// Host side of the drop-in boundary: copies the scene into HBM (bricked density + majorant grid,
+// threaded BVH), restates the per-frame camera constants of BaseIntegrator::renderPartial, and
+// launches the integrator kernels in sample passes that fit the staging buffer.  Nothing here
+// touches oracle/ — if the GPU or the HIP runtime is missing every entry point fails with
+// VR_ERR_NO_DEVICE / VR_ERR_HIP; there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vr_backend.h"
+#include "vr_kernels.h"
+
+using namespace vr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// ---------------------------------------------------------------------------------------------
+// set-up kernels
+// ---------------------------------------------------------------------------------------------
+
+// dense (k fastest) -> 8^3 bricks, padding with `background`
+__global__ void __launch_bounds__(256) k_rebrick(const float* __restrict__ dense, float* __restrict__ bricks, int dx, int dy,
+                                                 int dz, int nbx, int nby, int nbz, float background)
+{
+    const size_t total = (size_t)nbx * nby * nbz * 512;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t local = (uint32_t)(o & 511);
+        size_t         b = o >> 9;
+        const int bk = (int)(b % nbz); b /= nbz;
+        const int bj = (int)(b % nby);
+        const int bi = (int)(b / nby);
+        const int i = bi * 8 + (int)(local >> 6), j = bj * 8 + (int)((local >> 3) & 7), k = bk * 8 + (int)(local & 7);
+        float     v = background;
+        if (i < dx && j < dy && k < dz) v = dense[((size_t)i * dy + j) * dz + k];
+        bricks[o] = v;
+    }
+}
+__global__ void __launch_bounds__(256) k_unbrick(const float* __restrict__ bricks, float* __restrict__ dense, int dx, int dy,
+                                                 int dz, int nby, int nbz)
+{
+    const size_t total = (size_t)dx * dy * dz;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int    k = (int)(o % dz);
+        const size_t q = o / dz;
+        const int    j = (int)(q % dy), i = (int)(q / dy);
+        const size_t b = ((size_t)(i >> 3) * nby + (j >> 3)) * nbz + (k >> 3);
+        dense[o] = bricks[(b << 9) | ((i & 7) << 6) | ((j & 7) << 3) | (k & 7)];
+    }
+}
+// one wave per brick: majorant[b] = max over the brick's 512 voxels
+__global__ void __launch_bounds__(256) k_majorant(const float* __restrict__ bricks, float* __restrict__ majorant, uint32_t nbricks)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int      lane = threadIdx.x & 63;
+    if (wave >= nbricks) return;
+    const float4* src = reinterpret_cast<const float4*>(bricks + ((size_t)wave << 9)) + lane * 2;
+    const float4  a = src[0], b = src[1];
+    float m = fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) majorant[wave] = m;
+}
+
+// Ken Perlin's reference permutation — the table of Utils/PerlinNoiseSampler.cpp:11-28 (data)
+__constant__ uint8_t c_perm[256] = {
+    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142, 8,   99,
+    37,  240, 21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203, 117, 35,  11,  32,
+    57,  177, 33,  88,  237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165, 71,  134, 139, 48,  27,  166,
+    77,  146, 158, 231, 83,  111, 229, 122, 60,  211, 133, 230, 220, 105, 92,  41,  55,  46,  245, 40,  244, 102, 143, 54,
+    65,  25,  63,  161, 1,   216, 80,  73,  209, 76,  132, 187, 208, 89,  18,  169, 200, 196, 135, 130, 116, 188, 159, 86,
+    164, 100, 109, 198, 173, 186, 3,   64,  52,  217, 226, 250, 124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212,
+    207, 206, 59,  227, 47,  16,  58,  17,  182, 189, 28,  42,  223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,
+    221, 153, 101, 155, 167, 43,  172, 9,   129, 22,  39,  253, 19,  98,  108, 110, 79,  113, 224, 232, 178, 185, 112, 104,
+    218, 246, 97,  228, 251, 34,  242, 193, 238, 210, 144, 12,  191, 179, 162, 241, 81,  51,  145, 235, 249, 14,  239, 107,
+    49,  192, 214, 31,  181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,   150, 254, 138, 236, 205, 93,
+    222, 114, 67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180
+};
+__device__ __forceinline__ int pp(int i) { return c_perm[i & 255]; }
+__device__ __forceinline__ float pn_fade(float t) { return t * t * t * (t * (t * 6 - 15) + 10); }        // :32
+__device__ __forceinline__ float pn_lerp(float t, float a, float b) { return a + t * (b - a); }            // :33
+__device__ __forceinline__ float pn_grad(int hash, float x, float y, float z)                              // :34-40
+{
+    int   h = hash & 15;
+    float u = h < 8 ? x : y;
+    float v = h < 4 ? y : (h == 12 || h == 14) ? x : z;
+    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+}
+__device__ float perlin_noise(float x, float y, float z)                                                   // :46-68
+{
+    int X = (int)floorf(x) & 255, Y = (int)floorf(y) & 255, Z = (int)floorf(z) & 255;
+    x -= floorf(x); y -= floorf(y); z -= floorf(z);
+    float u = pn_fade(x), v = pn_fade(y), w = pn_fade(z);
+    int A = pp(X) + Y, AA = pp(A) + Z, AB = pp(A + 1) + Z;
+    int B = pp(X + 1) + Y, BA = pp(B) + Z, BB = pp(B + 1) + Z;
+    return pn_lerp(w,
+        pn_lerp(v, pn_lerp(u, pn_grad(pp(AA), x, y, z), pn_grad(pp(BA), x - 1, y, z)),
+                   pn_lerp(u, pn_grad(pp(AB), x, y - 1, z), pn_grad(pp(BB), x - 1, y - 1, z))),
+        pn_lerp(v, pn_lerp(u, pn_grad(pp(AA + 1), x, y, z - 1), pn_grad(pp(BA + 1), x - 1, y, z - 1)),
+                   pn_lerp(u, pn_grad(pp(AB + 1), x, y - 1, z - 1), pn_grad(pp(BB + 1), x - 1, y - 1, z - 1))));
+}
+// the synthetic cloud of BASELINE configs 2-4, written straight into brick order
+// (same expression sequence as the oracle's cloud_density)
+__global__ void __launch_bounds__(256) k_cloud(float* __restrict__ bricks, int n, int nb, float R)
+{
+    const size_t total = (size_t)nb * nb * nb * 512;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t local = (uint32_t)(o & 511);
+        size_t         b = o >> 9;
+        const int bk = (int)(b % nb); b /= nb;
+        const int bj = (int)(b % nb);
+        const int bi = (int)(b / nb);
+        const int i = bi * 8 + (int)(local >> 6), j = bj * 8 + (int)((local >> 3) & 7), k = bk * 8 + (int)(local & 7);
+        const float half = 0.5f * (float)n;
+        const float px = ((float)i + 0.5f) - half, py = ((float)j + 0.5f) - half, pz = ((float)k + 0.5f) - half;
+        const float r = sqrtf(px * px + py * py + pz * pz);
+        float t = 1.0f - r / R;
+        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        const float fall = t * t * (3.0f - 2.0f * t);
+        float d = 0.0f;
+        if (fall > 0.0f) {
+            float f = 4.0f / (float)n, amp = 1.0f, sum = 0.0f;
+            for (int oc = 0; oc < 4; ++oc) {
+                sum = sum + amp * perlin_noise(px * f + 17.0f, py * f + 17.0f, pz * f + 17.0f);
+                f = f * 2.0f;
+                amp = amp * 0.5f;
+            }
+            d = fall * (sum > 0.0f ? sum : 0.0f);
+        }
+        bricks[o] = d;
+    }
+}
+
+// max channel of an RGB buffer (BaseIntegrator.cpp:199-209): non-negative floats compare like ints
+__global__ void __launch_bounds__(256) k_max_channel(const float* __restrict__ rgb, size_t n, int* __restrict__ out_bits)
+{
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = rgb[i];
+        if (v > m) m = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_int(m));
+}
+// extended Reinhard (BaseIntegrator.cpp:211-220)
+__global__ void __launch_bounds__(256) k_tonemap(float* __restrict__ rgb, size_t n, float max_white2)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float p = rgb[i];
+        float numerator = p * ((p / max_white2) + 1.0f);
+        rgb[i] = numerator / (p + 1.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host restatements of the per-frame constants
+// ---------------------------------------------------------------------------------------------
+
+// BaseIntegrator::assignPointToQuadrant (BaseIntegrator.cpp:112-129)
+void quadrant_offset(int i, int total, float& ox, float& oy)
+{
+    ox = 0.0f; oy = 0.0f;
+    if (total < 4) return;
+    if (total == 4) {
+        ox = (i == 0 || i == 1) ? 0.25f : -0.25f;
+        oy = (i == 0 || i == 2) ? 0.25f : -0.25f;
+        return;
+    }
+    float rx, ry;
+    quadrant_offset(i % (total / 4), total / 4, rx, ry);
+    const float value = 1.0f / total;
+    float sx, sy;
+    if (i < total / 4.0f)          { sx = value;  sy = value; }
+    else if (i < 2 * total / 4.0f) { sx = value;  sy = -value; }
+    else if (i < 3 * total / 4.0f) { sx = -value; sy = value; }
+    else                           { sx = -value; sy = -value; }
+    ox = sx + rx; oy = sy + ry;
+}
+
+struct Pass { hipEvent_t e0, e1; };
+
+} // namespace
+
+struct vr_backend {
+    int           device = 0;
+    hipStream_t   stream = nullptr;
+    std::string   err;
+    int           num_cu = 256;
+    int           mode = VR_MODE_FAST;
+    uint64_t      seed = 0x5EED0001ull;
+    uint64_t      sample_budget = 4ull << 30;
+
+    // density / temperature
+    bool     has_density = false, has_temperature = false;
+    float*   d_bricks = nullptr;  float* d_major = nullptr;  GridDev grid{};
+    float*   d_tbricks = nullptr; GridDev tgrid{};
+    float    inv_mat[9]{}, vec[3]{};
+    float    bmin[3]{}, bmax1[3]{};
+    float    max_value = 0.0f;
+
+    // mesh
+    bool      has_mesh = false;
+    BvhNode*  d_nodes = nullptr; TriDev* d_tris = nullptr; uint32_t* d_p2s = nullptr; float* d_dissolve = nullptr;
+    uint32_t  nnodes = 0, nshapes = 0;
+
+    // scratch
+    float*    d_samples = nullptr; size_t samples_cap = 0;
+    float*    d_rows = nullptr;    size_t rows_cap = 0;
+    float2*   d_offsets = nullptr; size_t offsets_cap = 0;
+    uint32_t* d_work = nullptr;
+    Counters* d_counters = nullptr;
+    int*      d_maxbits = nullptr;
+
+    std::vector<Pass> passes;
+    size_t            passes_used = 0;
+    vr_render_stats   stats{};
+};
+
+namespace {
+
+int fail(vr_backend* b, int code, const char* fmt, ...)
+{
+    char    buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (b) b->err = buf; else g_create_error = buf;
+    return code;
+}
+#define HIP_TRY(b, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail((b), e_ == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP, "%s: %s", #call, \
+                        hipGetErrorString(e_));                                                       \
+    } while (0)
+
+int use_device(vr_backend* b)
+{
+    HIP_TRY(b, hipSetDevice(b->device));
+    return VR_OK;
+}
+
+template <typename T>
+int ensure(vr_backend* b, T*& ptr, size_t& cap, size_t count)
+{
+    if (count <= cap && ptr) return VR_OK;
+    if (ptr) { HIP_TRY(b, hipFree(ptr)); ptr = nullptr; cap = 0; }
+    HIP_TRY(b, hipMalloc((void**)&ptr, count * sizeof(T)));
+    cap = count;
+    return VR_OK;
+}
+
+int grid_blocks(size_t n, int cap = 8192)
+{
+    size_t g = (n + 255) / 256;
+    return (int)std::max<size_t>(1, std::min<size_t>(g, (size_t)cap));
+}
+
+int upload_grid(vr_backend* b, const vr_grid_desc* g, float*& d_bricks, GridDev& out)
+{
+    int64_t d[3];
+    for (int i = 0; i < 3; ++i) {
+        d[i] = (int64_t)g->bbox_max[i] - g->bbox_min[i] + 1;
+        if (d[i] <= 0 || d[i] > 4096) return fail(b, VR_ERR_INVALID_ARG, "grid extent %lld on axis %d out of range", (long long)d[i], i);
+    }
+    if (!g->voxels) return fail(b, VR_ERR_INVALID_ARG, "grid voxels == NULL");
+    const size_t nvox = (size_t)d[0] * d[1] * d[2];
+    const int    nb[3] = { (int)((d[0] + 7) / 8), (int)((d[1] + 7) / 8), (int)((d[2] + 7) / 8) };
+    const size_t nbricks = (size_t)nb[0] * nb[1] * nb[2];
+    if ((nbricks << 9) >= (1ull << 32)) return fail(b, VR_ERR_INVALID_ARG, "grid too large for 32-bit voxel offsets");
+    float* d_dense = nullptr;
+    HIP_TRY(b, hipMalloc((void**)&d_dense, nvox * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d_dense, g->voxels, nvox * sizeof(float), hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) {
+        if (d_bricks) { (void)hipFree(d_bricks); d_bricks = nullptr; }
+        e = hipMalloc((void**)&d_bricks, nbricks * 512 * sizeof(float));
+    }
+    if (e == hipSuccess) {
+        k_rebrick<<<grid_blocks(nbricks * 512), 256, 0, b->stream>>>(d_dense, d_bricks, (int)d[0], (int)d[1], (int)d[2], nb[0], nb[1],
+                                                                      nb[2], g->background);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d_dense);
+    if (e != hipSuccess) return fail(b, e == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP, "grid upload: %s", hipGetErrorString(e));
+    out.bricks = d_bricks;
+    for (int i = 0; i < 3; ++i) { out.min[i] = g->bbox_min[i]; out.dim[i] = (int32_t)d[i]; out.nb[i] = nb[i]; }
+    out.background = g->background;
+    return VR_OK;
+}
+
+int build_majorant(vr_backend* b)
+{
+    const uint32_t nbricks = (uint32_t)b->grid.nb[0] * b->grid.nb[1] * b->grid.nb[2];
+    if (b->d_major) { (void)hipFree(b->d_major); b->d_major = nullptr; }
+    HIP_TRY(b, hipMalloc((void**)&b->d_major, (size_t)nbricks * sizeof(float)));
+    k_majorant<<<(nbricks + 3) / 4, 256, 0, b->stream>>>(b->d_bricks, b->d_major, nbricks);
+    HIP_TRY(b, hipGetLastError());
+    std::vector<float> h(nbricks);
+    HIP_TRY(b, hipMemcpyAsync(h.data(), b->d_major, (size_t)nbricks * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    // nanovdb::getExtrema(grid, bbox).max() (SceneLoader.cpp:219): padding voxels hold the background,
+    // which getExtrema also sees for inactive voxels inside the bbox
+    float m = h[0];
+    for (uint32_t i = 1; i < nbricks; ++i) if (h[i] > m) m = h[i];
+    b->max_value = m;
+    return VR_OK;
+}
+
+void set_map(vr_backend* b, const float* inv_mat, const float* vec, const int32_t* bmin, const int32_t* bmax)
+{
+    memcpy(b->inv_mat, inv_mat, sizeof b->inv_mat);
+    memcpy(b->vec, vec, sizeof b->vec);
+    for (int i = 0; i < 3; ++i) { b->bmin[i] = (float)bmin[i]; b->bmax1[i] = (float)(bmax[i] + 1); }   // Ray.h:401
+}
+
+// ---- threaded BVH (replaces the Embree scene, SceneLoader.cpp:150-199) ----
+struct BuildTri { float lo[3], hi[3], c[3]; uint32_t prim; };
+
+void build_bvh(std::vector<BuildTri>& t, uint32_t first, uint32_t count, std::vector<BvhNode>& nodes, std::vector<uint32_t>& order)
+{
+    BvhNode nd{};
+    float   clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int a = 0; a < 3; ++a) { nd.lo[a] = INFINITY; nd.hi[a] = -INFINITY; }
+    for (uint32_t i = first; i < first + count; ++i)
+        for (int a = 0; a < 3; ++a) {
+            nd.lo[a] = std::min(nd.lo[a], t[i].lo[a]); nd.hi[a] = std::max(nd.hi[a], t[i].hi[a]);
+            clo[a] = std::min(clo[a], t[i].c[a]); chi[a] = std::max(chi[a], t[i].c[a]);
+        }
+    // conservative pad: Moeller-Trumbore accepts points a few ulp outside the triangle's box
+    for (int a = 0; a < 3; ++a) {
+        const float ext = nd.hi[a] - nd.lo[a];
+        const float mag = std::max(std::fabs(nd.lo[a]), std::fabs(nd.hi[a]));
+        const float pad = 1e-4f * std::max(ext, 1e-3f) + 1e-5f * mag;
+        nd.lo[a] -= pad; nd.hi[a] += pad;
+    }
+    const uint32_t me = (uint32_t)nodes.size();
+    nodes.push_back(nd);
+    int axis = 0;
+    for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+    if (count <= 4 || !(chi[axis] > clo[axis])) {
+        nodes[me].first = (uint32_t)order.size();
+        nodes[me].count = count;
+        for (uint32_t i = first; i < first + count; ++i) order.push_back(i);
+    } else {
+        const uint32_t mid = count / 2;
+        std::nth_element(t.begin() + first, t.begin() + first + mid, t.begin() + first + count,
+                         [axis](const BuildTri& x, const BuildTri& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.prim < y.prim); });
+        nodes[me].first = 0; nodes[me].count = 0;
+        build_bvh(t, first, mid, nodes, order);
+        build_bvh(t, first + mid, count - mid, nodes, order);
+    }
+    nodes[me].skip = (uint32_t)nodes.size();
+}
+
+struct Frame {
+    CameraDev cam;
+    uint32_t  spp;
+};
+
+// renderPartial's constants (BaseIntegrator.cpp:288-312) and Utils::rotate's matrix (Utils.cpp:30-53)
+int make_camera(vr_backend* b, const vr_options_pod* o, CameraDev& c)
+{
+    memset(&c, 0, sizeof c);
+    const float width = o->widthReference > 0.0f ? (float)o->widthReference : (float)o->width;
+    const float height = o->heightReference > 0.0f ? (float)o->heightReference : (float)o->height;
+    const float half_fov = (float)(o->fov * 0.5);
+    const float rad = (float)(half_fov * M_PI / 180);       // Utils::deg2rad
+    const float scale = tanf(rad);
+    const float aspect = width / height;
+    const float x = (float)((2 * (0.5) / width - 1) * aspect * scale);
+    const float y = (float)((1 - 2 * (0.5) / height) * scale);
+    const float x1 = (float)((2 * (1.5) / width - 1) * aspect * scale);
+    const float y1 = (float)((1 - 2 * (1.5) / height) * scale);
+    c.scale = scale; c.aspect = aspect; c.pixel_w = x1 - x; c.pixel_h = y1 - y;
+    c.ref_w = o->widthReference > 0 ? o->widthReference : o->width;
+    c.ref_h = o->heightReference > 0 ? o->heightReference : o->height;
+    c.x0 = o->widthStartOffset; c.y0 = o->heightStartOffset;
+    c.width = o->width;
+    for (int i = 0; i < 3; ++i) c.pos[i] = o->cameraPosition[i];
+    c.has_rot = (o->cameraRotation[1] != 0 || o->cameraRotation[0] != 0 || o->cameraRotation[2] != 0) ? 1 : 0;  // BaseIntegrator.cpp:56
+    if (c.has_rot) {
+        // rotate(pitch = rot.y, roll = rot.x, yaw = rot.z)                                       BaseIntegrator.cpp:57
+        float pitch = o->cameraRotation[1], roll = o->cameraRotation[0], yaw = o->cameraRotation[2];
+        pitch = (float)((pitch * M_PI) / 180); roll = (float)((roll * M_PI) / 180); yaw = (float)((yaw * M_PI) / 180);
+        const float cosa = (float)cos((double)yaw), sina = (float)sin((double)yaw);
+        const float cosb = (float)cos((double)pitch), sinb = (float)sin((double)pitch);
+        const float cosc = (float)cos((double)roll), sinc = (float)sin((double)roll);
+        c.rot[0] = cosa * cosb; c.rot[1] = cosa * sinb * sinc - sina * cosc; c.rot[2] = cosa * sinb * cosc + sina * sinc;
+        c.rot[3] = sina * cosb; c.rot[4] = sina * sinb * sinc + cosa * cosc; c.rot[5] = sina * sinb * cosc - cosa * sinc;
+        c.rot[6] = -sinb;       c.rot[7] = cosb * sinc;                      c.rot[8] = cosb * cosc;
+    }
+    // quadrant offsets per sub-sample
+    const uint32_t spp = o->rayPerPixelCount;
+    if (ensure(b, b->d_offsets, b->offsets_cap, (size_t)spp)) return VR_ERR_HIP;
+    std::vector<float2> off(spp);
+    for (uint32_t s = 0; s < spp; ++s) quadrant_offset((int)s, (int)spp, off[s].x, off[s].y);
+    HIP_TRY(b, hipMemcpyAsync(b->d_offsets, off.data(), spp * sizeof(float2), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));   // `off` goes out of scope
+    c.offsets = b->d_offsets;
+    c.spp = spp;
+    return VR_OK;
+}
+
+float ulp_of(float v)
+{
+    v = std::fabs(v);
+    return std::nextafter(v, INFINITY) - v;
+}
+
+int validate(vr_backend* b, const vr_options_pod* o, int integrator)
+{
+    if (!o) return fail(b, VR_ERR_INVALID_ARG, "options == NULL");
+    if (integrator < 0 || integrator >= VR_INTEGRATOR_COUNT) return fail(b, VR_ERR_INVALID_ARG, "unknown integrator id %d", integrator);
+    if (o->width == 0 || o->height == 0 || o->rayPerPixelCount == 0) return fail(b, VR_ERR_INVALID_ARG, "width, height and rayPerPixelCount must be > 0");
+    if (o->width + o->widthStartOffset > 65536u || o->height + o->heightStartOffset > 65536u)
+        return fail(b, VR_ERR_INVALID_ARG, "image coordinates must stay below 65536 (Philox pixel key)");
+    if (o->maxDepth > 255) return fail(b, VR_ERR_INVALID_ARG, "maxDepth is a uint8_t in the reference (Types.h:101)");
+    if (o->useImportanceSampling) return fail(b, VR_ERR_UNSUPPORTED, "importanceSampling is not implemented on the GPU path yet");
+    if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
+        if (!b->has_density) return fail(b, VR_ERR_NO_DENSITY, "tracking integrators need a density grid (SceneLoader.cpp:212-213)");
+        // every step must advance t in float, or the reference's loops never end
+        if (!(o->stepSizeMin > 0.0f) || !(o->stepSizeMax >= o->stepSizeMin))
+            return fail(b, VR_ERR_INVALID_ARG, "stepSize min must be > 0 and <= max (the reference would not terminate)");
+        float diag = 0.0f, dist = 0.0f;
+        for (int i = 0; i < 3; ++i) {
+            const float ext = b->bmax1[i] - b->bmin[i];
+            diag += ext * ext;
+            float e = 0.0f;
+            for (int k = 0; k < 3; ++k) e += b->inv_mat[3 * i + k] * (o->cameraPosition[k] - b->vec[k]);
+            const float c = 0.5f * (b->bmax1[i] + b->bmin[i]);
+            dist += (e - c) * (e - c);
+        }
+        const float tmax = std::sqrt(dist) + 2.0f * std::sqrt(diag);
+        if (o->stepSizeMin < ulp_of(tmax))
+            return fail(b, VR_ERR_INVALID_ARG, "stepSize min %g is below float resolution at ray parameter %g", o->stepSizeMin, tmax);
+        if (std::sqrt(diag) / o->stepSizeMin > 1.0e8f)
+            return fail(b, VR_ERR_INVALID_ARG, "stepSize min %g needs more than 1e8 steps across the grid", o->stepSizeMin);
+    } else {
+        if (!b->has_mesh) return fail(b, VR_ERR_NO_MESH, "marching integrators need a mesh");
+    }
+    return VR_OK;
+}
+
+template <typename K, typename P>
+int launch_cap(vr_backend* b, K kernel, const P&, int& blocks_per_cu)
+{
+    int nb = 0;
+    HIP_TRY(b, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0));
+    blocks_per_cu = std::max(1, std::min(nb, 8));
+    return VR_OK;
+}
+
+int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint32_t row_first, uint32_t row_stride,
+                   uint32_t row_count, float* d_out)
+{
+    int rc = use_device(b);
+    if (rc) return rc;
+    rc = validate(b, o, integrator);
+    if (rc) return rc;
+    if (row_count == 0) return VR_OK;
+    if (row_stride == 0) return fail(b, VR_ERR_INVALID_ARG, "row_stride must be > 0");
+    if ((uint64_t)row_first + (uint64_t)(row_count - 1) * row_stride >= o->height)
+        return fail(b, VR_ERR_INVALID_ARG, "row set exceeds height %u", o->height);
+    if (!d_out) return fail(b, VR_ERR_INVALID_ARG, "output == NULL");
+
+    CameraDev cam;
+    rc = make_camera(b, o, cam);
+    if (rc) return rc;
+    cam.row_first = row_first; cam.row_stride = row_stride; cam.nrows = row_count;
+
+    const uint32_t spp = o->rayPerPixelCount;
+    const uint64_t npix = (uint64_t)row_count * o->width;
+    if (npix * 3 >= (1ull << 32)) return fail(b, VR_ERR_INVALID_ARG, "row set too large");
+    uint64_t per_pass = std::max<uint64_t>(1, b->sample_budget / (npix * 12));
+    per_pass = std::min<uint64_t>(per_pass, spp);
+    per_pass = std::min<uint64_t>(per_pass, std::max<uint64_t>(1, 0x7fffffffull / npix));
+    if (npix * per_pass >= (1ull << 31)) return fail(b, VR_ERR_INVALID_ARG, "row set too large for one pass");
+    rc = ensure(b, b->d_samples, b->samples_cap, (size_t)(npix * per_pass * 3));
+    if (rc) return rc;
+
+    WorkDev work{};
+    work.counter = b->d_work; work.samples = b->d_samples; work.counters = b->d_counters;
+    work.key0 = (uint32_t)b->seed; work.key1 = (uint32_t)(b->seed >> 32);
+    work.step_limit = 1u << 28;
+
+    HIP_TRY(b, hipMemsetAsync(b->d_counters, 0, sizeof(Counters), b->stream));
+    b->passes_used = 0;
+    const bool exact = b->mode == VR_MODE_EXACT;
+
+    for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)per_pass) {
+        const uint32_t sc = (uint32_t)std::min<uint64_t>(per_pass, spp - s0);
+        cam.s_first = s0; cam.s_count = sc;
+        work.nitems = (uint32_t)(npix * sc);
+        if (b->passes_used == b->passes.size()) {
+            Pass p{};
+            HIP_TRY(b, hipEventCreate(&p.e0));
+            HIP_TRY(b, hipEventCreate(&p.e1));
+            b->passes.push_back(p);
+        }
+        Pass& ev = b->passes[b->passes_used++];
+        HIP_TRY(b, hipMemsetAsync(b->d_work, 0, sizeof(uint32_t), b->stream));
+
+        if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
+            TrackParams p{};
+            p.cam = cam; p.work = work;
+            p.density = b->grid; p.temperature = b->tgrid; p.has_temperature = b->has_temperature ? 1 : 0;
+            memcpy(p.inv_mat, b->inv_mat, sizeof p.inv_mat); memcpy(p.vec, b->vec, sizeof p.vec);
+            memcpy(p.bmin, b->bmin, sizeof p.bmin); memcpy(p.bmax1, b->bmax1, sizeof p.bmax1);
+            p.sigma_a = o->sigma_a; p.sigma_s = o->sigma_s;
+            p.sigma_maj = b->max_value * (o->sigma_a + o->sigma_s);          // IntegratorRatioTracking.cpp:42-45
+            p.t_min = o->stepSizeMin; p.t_max = o->stepSizeMax; p.step_mult = o->stepSizeMultiplier;
+            p.light_mult = o->lightRayDensityMultiplier; p.shadow_mult = o->shadowRayDensityMultiplier;
+            p.g = o->heyneyGreensteinG;
+            for (int i = 0; i < 3; ++i) {
+                p.light[i] = o->lightPosition[i]; p.light_color[i] = o->lightColor[i]; p.emission[i] = o->emissionColor[i];
+                p.medium[i] = o->mediumColor[i]; p.background[i] = o->backgroundColor[i];
+            }
+            p.max_depth = o->maxDepth;
+            void (*kern)(const TrackParams) =
+                integrator == VR_INTEGRATOR_RATIO_TRACKING
+                    ? (exact ? vr_track_kernel<INTEG_RATIO, true> : vr_track_kernel<INTEG_RATIO, false>)
+                    : (exact ? vr_track_kernel<INTEG_DELTA, true> : vr_track_kernel<INTEG_DELTA, false>);
+            int per_cu = 4;
+            rc = launch_cap(b, kern, p, per_cu);
+            if (rc) return rc;
+            const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_cu * b->num_cu, (work.nitems + 255ull) / 256));
+            HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
+            HIP_TRY(b, hipGetLastError());
+            HIP_TRY(b, hipEventRecord(ev.e1, b->stream));
+        } else {
+            MarchParams p{};
+            p.cam = cam; p.work = work;
+            p.mesh.nodes = b->d_nodes; p.mesh.tris = b->d_tris; p.mesh.prim_to_shape = b->d_p2s;
+            p.mesh.shape_dissolve = b->d_dissolve; p.mesh.nnodes = b->nnodes;
+            p.sigma_a = o->sigma_a; p.sigma_s = o->sigma_s; p.g = o->heyneyGreensteinG;
+            for (int i = 0; i < 3; ++i) {
+                p.light[i] = o->lightPosition[i]; p.light_color[i] = o->lightColor[i]; p.background[i] = o->backgroundColor[i];
+            }
+            p.max_depth = o->maxDepth;
+            void (*kern)(const MarchParams) =
+                integrator == VR_INTEGRATOR_HOMOGENEOUS_RAY_MARCHER_NEE
+                    ? (exact ? vr_march_kernel<false, true> : vr_march_kernel<false, false>)
+                    : (exact ? vr_march_kernel<true, true> : vr_march_kernel<true, false>);
+            const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(8ull * b->num_cu, (work.nitems + 255ull) / 256));
+            HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
+            HIP_TRY(b, hipGetLastError());
+            HIP_TRY(b, hipEventRecord(ev.e1, b->stream));
+        }
+        const uint32_t nchan = (uint32_t)(npix * 3);
+        vr_resolve_kernel<<<(nchan + 255) / 256, 256, 0, b->stream>>>(b->d_samples, d_out, (uint32_t)npix, sc, s0 == 0 ? 1 : 0,
+                                                                      s0 + sc >= spp ? 1 : 0, (float)spp);
+        HIP_TRY(b, hipGetLastError());
+    }
+    return VR_OK;
+}
+
+int collect(vr_backend* b)
+{
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    Counters c{};
+    HIP_TRY(b, hipMemcpy(&c, b->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    b->stats.path_samples = c.path_samples; b->stats.density_lookups = c.density_lookups;
+    b->stats.scatter_events = c.scatter_events; b->stats.shadow_rays = c.shadow_rays;
+    b->stats.ray_queries = c.ray_queries; b->stats.step_limit_hits = c.step_limit_hits;
+    if (c.step_limit_hits) return fail(b, VR_ERR_STEP_LIMIT, "%llu paths hit the per-path step cap", (unsigned long long)c.step_limit_hits);
+    return VR_OK;
+}
+
+} // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+void vr_abi_sizes(uint32_t out[4])
+{
+    out[0] = (uint32_t)sizeof(vr_options_pod); out[1] = (uint32_t)sizeof(vr_grid_desc);
+    out[2] = (uint32_t)sizeof(vr_mesh_desc);   out[3] = (uint32_t)sizeof(vr_render_stats);
+}
+
+const char* vr_backend_last_error(const vr_backend* b) { return b ? b->err.c_str() : g_create_error.c_str(); }
+
+int vr_backend_create(int device, vr_backend** out)
+{
+    if (!out) return fail(nullptr, VR_ERR_INVALID_ARG, "out == NULL");
+    *out = nullptr;
+    int        n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, VR_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, VR_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+    vr_backend* b = new vr_backend;
+    b->device = device;
+    auto bail = [&](const char* what, hipError_t err) {
+        int code = fail(nullptr, VR_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+        delete b;
+        return code;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    b->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipMalloc((void**)&b->d_work, 256)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&b->d_counters, sizeof(Counters))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&b->d_maxbits, 256)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(b->d_counters, 0, sizeof(Counters))) != hipSuccess) return bail("hipMemset", e);
+    *out = b;
+    return VR_OK;
+}
+
+void vr_backend_destroy(vr_backend* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    void* ptrs[] = { b->d_bricks, b->d_major, b->d_tbricks, b->d_nodes, b->d_tris, b->d_p2s, b->d_dissolve, b->d_samples,
+                     b->d_rows, b->d_offsets, b->d_work, b->d_counters, b->d_maxbits };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (Pass& p : b->passes) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int vr_backend_set_mode(vr_backend* b, int mode)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    if (mode != VR_MODE_EXACT && mode != VR_MODE_FAST) return fail(b, VR_ERR_INVALID_ARG, "unknown mode %d", mode);
+    b->mode = mode;
+    return VR_OK;
+}
+int vr_backend_set_seed(vr_backend* b, uint64_t seed)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    b->seed = seed;
+    return VR_OK;
+}
+int vr_backend_set_sample_buffer_bytes(vr_backend* b, uint64_t bytes)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    if (bytes < 12) return fail(b, VR_ERR_INVALID_ARG, "sample buffer must hold at least one sample");
+    b->sample_budget = bytes;
+    return VR_OK;
+}
+
+int vr_backend_set_density(vr_backend* b, const vr_grid_desc* density, const vr_grid_desc* temperature)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    if (!density) return fail(b, VR_ERR_INVALID_ARG, "density == NULL");
+    int rc = use_device(b);
+    if (rc) return rc;
+    b->has_density = false; b->has_temperature = false;
+    rc = upload_grid(b, density, b->d_bricks, b->grid);
+    if (rc) return rc;
+    set_map(b, density->inv_mat, density->vec, density->bbox_min, density->bbox_max);
+    rc = build_majorant(b);
+    if (rc) return rc;
+    if (density->max_value >= 0.0f) b->max_value = density->max_value;   // the caller's getExtrema result
+    if (temperature) {
+        rc = upload_grid(b, temperature, b->d_tbricks, b->tgrid);
+        if (rc) return rc;
+        b->has_temperature = true;
+    }
+    b->has_density = true;
+    return VR_OK;
+}
+
+int vr_backend_generate_cloud(vr_backend* b, int n, float radius_voxels)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    if (n < 8 || n > 1536 || (n & 7)) return fail(b, VR_ERR_INVALID_ARG, "n must be a multiple of 8 in [8, 1536]");
+    if (!(radius_voxels > 0.0f)) return fail(b, VR_ERR_INVALID_ARG, "radius must be > 0");
+    int rc = use_device(b);
+    if (rc) return rc;
+    b->has_density = false; b->has_temperature = false;
+    const int    nb = n / 8;
+    const size_t nvox = (size_t)n * n * n;
+    if (b->d_bricks) { (void)hipFree(b->d_bricks); b->d_bricks = nullptr; }
+    HIP_TRY(b, hipMalloc((void**)&b->d_bricks, nvox * sizeof(float)));
+    k_cloud<<<grid_blocks(nvox, 16384), 256, 0, b->stream>>>(b->d_bricks, n, nb, radius_voxels);
+    HIP_TRY(b, hipGetLastError());
+    b->grid.bricks = b->d_bricks;
+    int32_t bmin[3], bmax[3];
+    for (int i = 0; i < 3; ++i) {
+        b->grid.min[i] = -(n / 2); b->grid.dim[i] = n; b->grid.nb[i] = nb;
+        bmin[i] = -(n / 2); bmax[i] = -(n / 2) + n - 1;
+    }
+    b->grid.background = 0.0f;
+    const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, zero[3] = { 0, 0, 0 };
+    set_map(b, ident, zero, bmin, bmax);
+    rc = build_majorant(b);
+    if (rc) return rc;
+    b->has_density = true;
+    return VR_OK;
+}
+
+int vr_backend_density_max(vr_backend* b, float* max_value)
+{
+    if (!b || !max_value) return VR_ERR_INVALID_ARG;
+    if (!b->has_density) return fail(b, VR_ERR_NO_DENSITY, "no density grid");
+    *max_value = b->max_value;
+    return VR_OK;
+}
+
+int vr_backend_read_density(vr_backend* b, float* voxels, uint64_t capacity, int32_t dims[3], int32_t bbox_min[3])
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    if (!b->has_density) return fail(b, VR_ERR_NO_DENSITY, "no density grid");
+    int rc = use_device(b);
+    if (rc) return rc;
+    const GridDev& g = b->grid;
+    if (dims) for (int i = 0; i < 3; ++i) dims[i] = g.dim[i];
+    if (bbox_min) for (int i = 0; i < 3; ++i) bbox_min[i] = g.min[i];
+    if (!voxels) return VR_OK;
+    const size_t nvox = (size_t)g.dim[0] * g.dim[1] * g.dim[2];
+    if (capacity < nvox) return fail(b, VR_ERR_INVALID_ARG, "buffer holds %llu floats, grid has %llu", (unsigned long long)capacity, (unsigned long long)nvox);
+    float* d_dense = nullptr;
+    HIP_TRY(b, hipMalloc((void**)&d_dense, nvox * sizeof(float)));
+    k_unbrick<<<grid_blocks(nvox), 256, 0, b->stream>>>(g.bricks, d_dense, g.dim[0], g.dim[1], g.dim[2], g.nb[1], g.nb[2]);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(voxels, d_dense, nvox * sizeof(float), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d_dense);
+    if (e != hipSuccess) return fail(b, VR_ERR_HIP, "read_density: %s", hipGetErrorString(e));
+    return VR_OK;
+}
+
+int vr_backend_set_mesh(vr_backend* b, const vr_mesh_desc* m)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    if (!m || !m->verts_xyz || !m->tri_idx || !m->prim_to_shape || !m->shape_dissolve || m->ntris == 0 || m->nshapes == 0)
+        return fail(b, VR_ERR_INVALID_ARG, "incomplete mesh description");
+    int rc = use_device(b);
+    if (rc) return rc;
+    b->has_mesh = false;
+    std::vector<BuildTri> bt(m->ntris);
+    for (uint32_t t = 0; t < m->ntris; ++t) {
+        if (m->prim_to_shape[t] >= m->nshapes) return fail(b, VR_ERR_INVALID_ARG, "prim_to_shape[%u] out of range", t);
+        for (int a = 0; a < 3; ++a) { bt[t].lo[a] = INFINITY; bt[t].hi[a] = -INFINITY; bt[t].c[a] = 0.0f; }
+        for (int v = 0; v < 3; ++v) {
+            const uint32_t vi = m->tri_idx[3 * (size_t)t + v];
+            if (vi >= m->nverts) return fail(b, VR_ERR_INVALID_ARG, "triangle %u references vertex %u of %u", t, vi, m->nverts);
+            for (int a = 0; a < 3; ++a) {
+                const float x = m->verts_xyz[3 * (size_t)vi + a];
+                bt[t].lo[a] = std::min(bt[t].lo[a], x); bt[t].hi[a] = std::max(bt[t].hi[a], x);
+                bt[t].c[a] += x * (1.0f / 3.0f);
+            }
+        }
+        bt[t].prim = t;
+    }
+    std::vector<BvhNode>  nodes;
+    std::vector<uint32_t> order;
+    build_bvh(bt, 0, m->ntris, nodes, order);
+    std::vector<TriDev> tris(order.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+        const uint32_t  prim = bt[order[k]].prim;
+        const uint32_t* idx = m->tri_idx + 3 * (size_t)prim;
+        const float *v0 = m->verts_xyz + 3 * (size_t)idx[0], *v1 = m->verts_xyz + 3 * (size_t)idx[1], *v2 = m->verts_xyz + 3 * (size_t)idx[2];
+        for (int a = 0; a < 3; ++a) { tris[k].v0[a] = v0[a]; tris[k].e1[a] = v1[a] - v0[a]; tris[k].e2[a] = v2[a] - v0[a]; }
+        tris[k].prim = prim;
+    }
+    void* old[] = { b->d_nodes, b->d_tris, b->d_p2s, b->d_dissolve };
+    for (void* p : old) if (p) (void)hipFree(p);
+    b->d_nodes = nullptr; b->d_tris = nullptr; b->d_p2s = nullptr; b->d_dissolve = nullptr;
+    HIP_TRY(b, hipMalloc((void**)&b->d_nodes, nodes.size() * sizeof(BvhNode)));
+    HIP_TRY(b, hipMalloc((void**)&b->d_tris, tris.size() * sizeof(TriDev)));
+    HIP_TRY(b, hipMalloc((void**)&b->d_p2s, (size_t)m->ntris * sizeof(uint32_t)));
+    HIP_TRY(b, hipMalloc((void**)&b->d_dissolve, (size_t)m->nshapes * sizeof(float)));
+    HIP_TRY(b, hipMemcpy(b->d_nodes, nodes.data(), nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    HIP_TRY(b, hipMemcpy(b->d_tris, tris.data(), tris.size() * sizeof(TriDev), hipMemcpyHostToDevice));
+    HIP_TRY(b, hipMemcpy(b->d_p2s, m->prim_to_shape, (size_t)m->ntris * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(b, hipMemcpy(b->d_dissolve, m->shape_dissolve, (size_t)m->nshapes * sizeof(float), hipMemcpyHostToDevice));
+    b->nnodes = (uint32_t)nodes.size(); b->nshapes = m->nshapes;
+    b->has_mesh = true;
+    return VR_OK;
+}
+
+int vr_backend_render_row_set_device(vr_backend* b, const vr_options_pod* o, int integrator, uint32_t row_first,
+                                     uint32_t row_stride, uint32_t row_count, void* d_rgb)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    return render_row_set(b, o, integrator, row_first, row_stride, row_count, (float*)d_rgb);
+}
+
+int vr_backend_synchronize(vr_backend* b)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    int rc = use_device(b);
+    if (rc) return rc;
+    return collect(b);
+}
+
+int vr_backend_render_rows(vr_backend* b, const vr_options_pod* o, int integrator, uint32_t from_row, uint32_t to_row, float* pix)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    if (!o) return fail(b, VR_ERR_INVALID_ARG, "options == NULL");
+    if (to_row < from_row || from_row < o->heightStartOffset) return fail(b, VR_ERR_INVALID_ARG, "bad row range [%u, %u)", from_row, to_row);
+    if (to_row == from_row) return VR_OK;
+    if (!pix) return fail(b, VR_ERR_INVALID_ARG, "pix == NULL");
+    int rc = use_device(b);
+    if (rc) return rc;
+    const uint32_t rows = to_row - from_row;
+    const size_t   nfl = (size_t)rows * o->width * 3;
+    rc = ensure(b, b->d_rows, b->rows_cap, nfl);
+    if (rc) return rc;
+    rc = render_row_set(b, o, integrator, from_row - o->heightStartOffset, 1, rows, b->d_rows);
+    if (rc) return rc;
+    HIP_TRY(b, hipMemcpyAsync(pix, b->d_rows, nfl * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    return collect(b);
+}
+
+int vr_backend_render(vr_backend* b, const vr_options_pod* o, int integrator, float* framebuffer)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    if (!o) return fail(b, VR_ERR_INVALID_ARG, "options == NULL");
+    return vr_backend_render_rows(b, o, integrator, o->heightStartOffset, o->heightStartOffset + o->height, framebuffer);
+}
+
+int vr_backend_last_stats(vr_backend* b, vr_render_stats* stats, float* kernel_ms, uint32_t* launches)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    int rc = use_device(b);
+    if (rc) return rc;
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    if (stats) *stats = b->stats;
+    float total = 0.0f;
+    for (size_t i = 0; i < b->passes_used; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(b, hipEventElapsedTime(&ms, b->passes[i].e0, b->passes[i].e1));
+        total += ms;
+    }
+    if (kernel_ms) *kernel_ms = total;
+    if (launches) *launches = (uint32_t)b->passes_used;
+    return VR_OK;
+}
+
+int vr_backend_max_channel_device(vr_backend* b, const void* d_rgb, uint64_t npixels, float* max_out)
+{
+    if (!b || !d_rgb || !max_out) return VR_ERR_INVALID_ARG;
+    int rc = use_device(b);
+    if (rc) return rc;
+    HIP_TRY(b, hipMemsetAsync(b->d_maxbits, 0, sizeof(int), b->stream));
+    if (npixels) {
+        k_max_channel<<<grid_blocks(npixels * 3, 1024), 256, 0, b->stream>>>((const float*)d_rgb, (size_t)npixels * 3, b->d_maxbits);
+        HIP_TRY(b, hipGetLastError());
+    }
+    int bits = 0;
+    HIP_TRY(b, hipMemcpyAsync(&bits, b->d_maxbits, sizeof bits, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    memcpy(max_out, &bits, sizeof bits);
+    return VR_OK;
+}
+
+int vr_backend_tonemap_device(vr_backend* b, void* d_rgb, uint64_t npixels, float max_white_in, float* max_white_out)
+{
+    if (!b || !d_rgb) return VR_ERR_INVALID_ARG;
+    float mw = max_white_in;
+    if (mw < 0.0f) {
+        int rc = vr_backend_max_channel_device(b, d_rgb, npixels, &mw);
+        if (rc) return rc;
+    } else {
+        int rc = use_device(b);
+        if (rc) return rc;
+    }
+    if (max_white_out) *max_white_out = mw;
+    if (npixels) {
+        k_tonemap<<<grid_blocks(npixels * 3, 2048), 256, 0, b->stream>>>((float*)d_rgb, (size_t)npixels * 3, mw * mw);
+        HIP_TRY(b, hipGetLastError());
+    }
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    return VR_OK;
+}
+
+int vr_rgb_to_u8(const float* rgb, uint32_t width, uint32_t height, uint8_t* out)
+{
+    if (!rgb || !out) return VR_ERR_INVALID_ARG;
+    const size_t n = (size_t)width * height * 3;
+    for (size_t i = 0; i < n; ++i) {
+        const float v = rgb[i];
+        const float m = (v < 1.0f) ? v : 1.0f;        // Utils::clamp(0, 1, v)              BaseIntegrator.cpp:21-23
+        const float c = (0.0f < m) ? m : 0.0f;
+        out[i] = (uint8_t)(255 * c);
+    }
+    return VR_OK;
+}
+
+} // extern "C"

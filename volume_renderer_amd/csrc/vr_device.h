@@ -1,0 +1,221 @@
+// vr_device.h — device-side building blocks of the integrator kernels (gfx950).
+//
+// Each block names the reference code whose results it must reproduce (paths relative to
+// /root/reference/VolumeRenderer/RayTracer/).  The whole library is compiled with
+// -ffp-contract=off: the only fused multiply-adds are the explicit fmaf calls, which are the
+// ones NanoVDB itself makes (nanovdb/util/Ray.h:156-158, nanovdb/NanoVDB.h:1533-1535).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vr_math.h"
+
+namespace vr {
+
+#define VR_FLT_MAX 3.402823466e+38f
+#define VR_PI_D 3.14159265358979323846
+
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 scale3(f3 a, float r) { return mk3(a.x * r, a.y * r, a.z * r); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // Utils.cpp:70-73
+__device__ __forceinline__ f3 cross3(f3 a, f3 b)                                                  // Utils.cpp:4-11
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ f3 normalize3(f3 v)                                                    // Utils.cpp:18-27
+{
+    float mag2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (mag2 > 0) {
+        float invMag = 1 / sqrtf(mag2);
+        return mk3(v.x * invMag, v.y * invMag, v.z * invMag);
+    }
+    return v;
+}
+// Utils::clamp(lo, hi, v) = std::max(lo, std::min(hi, v))                                          Utils.cpp:75-78
+__device__ __forceinline__ float clamp_lo_hi(float lo, float hi, float v)
+{
+    float m = (v < hi) ? v : hi;
+    return (lo < m) ? m : lo;
+}
+
+// ---- math policy ------------------------------------------------------------------------
+template <bool EXACT>
+struct Math;
+template <>
+struct Math<true> {
+    static __device__ __forceinline__ float log_(float x) { return vrm_logf(x); }
+    static __device__ __forceinline__ float exp_(float x) { return vrm_expf(x); }
+    static __device__ __forceinline__ void sincos_(float x, float& s, float& c) { vrm_sincosf(x, s, c); }
+};
+template <>
+struct Math<false> {
+    static __device__ __forceinline__ float log_(float x) { return __logf(x); }
+    static __device__ __forceinline__ float exp_(float x) { return __expf(x); }
+    static __device__ __forceinline__ void sincos_(float x, float& s, float& c) { s = __sinf(x); c = __cosf(x); }
+};
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter = (pixel, sample, stream tag, block) ---------
+// Replaces RandomGenerator (Utils/RandomGenerator.cpp:4-14): only the ranges of its draws are
+// contract.  pixel = (row << 16) | column in absolute image coordinates, so a pixel's stream does
+// not depend on crop, row partition or GPU count; tag = scatter count, | 0x80000000 for the
+// shadow march of that scatter event.
+struct Rng {
+    uint32_t pixel, sample, tag, n;
+    uint32_t b0, b1, b2, b3;
+};
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0;
+        uint32_t n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+__device__ __forceinline__ void rng_refill(Rng& g, uint32_t k0, uint32_t k1)
+{
+    philox4x32_10(g.pixel, g.sample, g.tag, g.n >> 2, k0, k1, g.b0, g.b1, g.b2, g.b3);
+}
+// next uniform in [0,1) with 24 bits
+__device__ __forceinline__ float rng_unit(Rng& g, uint32_t k0, uint32_t k1)
+{
+    uint32_t sel = g.n & 3u;
+    if (sel == 0u) rng_refill(g, k0, k1);
+    uint32_t w = sel == 0u ? g.b0 : (sel == 1u ? g.b1 : (sel == 2u ? g.b2 : g.b3));
+    g.n++;
+    return (float)(w >> 8) * (1.0f / 16777216.0f);
+}
+// RandomGenerator::getFloat(min, max): a + u*(b-a)
+__device__ __forceinline__ float rng_float(Rng& g, uint32_t k0, uint32_t k1, float lo, float hi)
+{
+    return (rng_unit(g, k0, k1) * (hi - lo)) + lo;
+}
+
+// ---- nanovdb::Ray<float> ----------------------------------------------------------------------
+struct Ray {
+    f3    eye, dir;
+    float t0, t1;
+};
+__device__ __forceinline__ f3 ray_at(f3 eye, f3 dir, float t)                                     // Ray.h:153-162
+{
+    return mk3(fmaf(t, dir.x, eye.x), fmaf(t, dir.y, eye.y), fmaf(t, dir.z, eye.z));
+}
+__device__ __forceinline__ f3 mat_mult(const float* m, f3 p)                                      // NanoVDB.h:1531-1536
+{
+    return mk3(fmaf(p.x, m[0], fmaf(p.y, m[1], p.z * m[2])), fmaf(p.x, m[3], fmaf(p.y, m[4], p.z * m[5])),
+               fmaf(p.x, m[6], fmaf(p.y, m[7], p.z * m[8])));
+}
+// Ray::clip(CoordBBox): slab test against [min, max+1], same comparisons, so NaNs from 0*inf
+// behave as in the reference                                                                   Ray.h:397-423,512-520
+__device__ __forceinline__ bool ray_clip(f3 eye, f3 dir, float& t0, float& t1, const float* bmin, const float* bmax1)
+{
+    // mInvDir(1/dir)                                                                            Ray.h:69
+    const float e[3] = { eye.x, eye.y, eye.z };
+    const float inv[3] = { 1 / dir.x, 1 / dir.y, 1 / dir.z };
+    float a0 = t0, a1 = t1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float a = bmin[i], b = bmax1[i];
+        if (a >= b) return false;
+        a = (a - e[i]) * inv[i];
+        b = (b - e[i]) * inv[i];
+        if (a > b) { float tmp = a; a = b; b = tmp; }
+        if (a > a0) a0 = a;
+        if (b < a1) a1 = b;
+        if (a0 > a1) return false;
+    }
+    t0 = a0; t1 = a1;
+    return true;
+}
+
+// ---- density field: dense grid of 8^3 bricks ---------------------------------------------------
+// Replaces ReadAccessor<float,0,1,2>::getValue(Coord::Floor(p)) (NanoVDB.h:5248-5263, :1133,
+// :818-821): nearest voxel by floor, background outside the bbox.  Brick b = (bi*nby + bj)*nbz + bk
+// holds voxel (i,j,k) at b*512 + ((i&7)<<6 | (j&7)<<3 | (k&7)) — NanoVDB's own leaf order.
+struct GridDev {
+    const float* bricks;
+    int32_t      min[3];
+    int32_t      dim[3]; // bbox extent in voxels (max - min + 1)
+    int32_t      nb[3];  // bricks per axis
+    float        background;
+};
+__device__ __forceinline__ uint32_t brick_offset(const GridDev& g, uint32_t i, uint32_t j, uint32_t k)
+{
+    uint32_t b = ((i >> 3) * (uint32_t)g.nb[1] + (j >> 3)) * (uint32_t)g.nb[2] + (k >> 3);
+    return (b << 9) | ((i & 7u) << 6) | ((j & 7u) << 3) | (k & 7u);
+}
+// One-entry register cache: consecutive steps inside one voxel (sub-voxel step sizes are the
+// reference's shipped regime) cost no memory instruction.
+struct VoxelCache {
+    uint32_t idx;
+    float    val;
+};
+__device__ __forceinline__ float grid_value(const GridDev& g, f3 p, VoxelCache& c)
+{
+    int32_t i = (int32_t)floorf(p.x) - g.min[0];
+    int32_t j = (int32_t)floorf(p.y) - g.min[1];
+    int32_t k = (int32_t)floorf(p.z) - g.min[2];
+    if ((uint32_t)i >= (uint32_t)g.dim[0] || (uint32_t)j >= (uint32_t)g.dim[1] || (uint32_t)k >= (uint32_t)g.dim[2])
+        return g.background;
+    uint32_t off = brick_offset(g, (uint32_t)i, (uint32_t)j, (uint32_t)k);
+    if (off != c.idx) {
+        c.val = g.bricks[off];
+        c.idx = off;
+    }
+    return c.val;
+}
+__device__ __forceinline__ float grid_value_nocache(const GridDev& g, f3 p)
+{
+    int32_t i = (int32_t)floorf(p.x) - g.min[0];
+    int32_t j = (int32_t)floorf(p.y) - g.min[1];
+    int32_t k = (int32_t)floorf(p.z) - g.min[2];
+    if ((uint32_t)i >= (uint32_t)g.dim[0] || (uint32_t)j >= (uint32_t)g.dim[1] || (uint32_t)k >= (uint32_t)g.dim[2])
+        return g.background;
+    return g.bricks[brick_offset(g, (uint32_t)i, (uint32_t)j, (uint32_t)k)];
+}
+
+// ---- phase function and direction sampling -----------------------------------------------------
+// PhaseFunction::henyey_greenstein                                                              PhaseFunction.cpp:4-8
+__device__ __forceinline__ float hg_phase(float g, float cos_theta)
+{
+    float denom = 1 + g * g - 2 * g * cos_theta;
+    return (float)(1 / (4 * VR_PI_D) * (1 - g * g) / (denom * sqrtf(denom)));
+}
+// DirectionSampler::sampleHenyeyGreenstein + ONB::Update                       DirectionSampler.cpp:38-72, ONB.cpp:5-22
+template <bool EXACT>
+__device__ __forceinline__ f3 hg_sample(float g, f3 direction, float xi, float xi2)
+{
+    f3 n = direction, s;
+    if (fabsf(n.x) > fabsf(n.z)) { s.x = -n.y; s.y = n.x; s.z = 0; }
+    else                         { s.x = 0; s.y = -n.z; s.z = n.y; }
+    s = normalize3(s);
+    f3 t = cross3(n, s);
+    f3 nd = normalize3(direction);
+    float cos_theta;
+    if (g != 0.0f) {
+        float aux = ((1 - g * g) / (1 - g + 2 * g * xi));
+        cos_theta = (1 + g * g - (aux * aux)) / (2 * g);
+    } else {
+        cos_theta = (float)(1.0 - 2.0 * (double)xi);
+    }
+    float c2 = 1.0f - cos_theta * cos_theta;
+    float sin_theta = sqrtf((0.0f < c2) ? c2 : 0.0f);
+    float phi = (float)((double)(xi2 * 2) * VR_PI_D);
+    float sp, cp;
+    Math<EXACT>::sincos_(phi, sp, cp);
+    f3 v1 = scale3(s, sin_theta * cp);
+    f3 v2 = scale3(t, sin_theta * sp);
+    f3 v3 = scale3(nd, cos_theta);
+    return add3(add3(v1, v2), v3);
+}
+
+} // namespace vr

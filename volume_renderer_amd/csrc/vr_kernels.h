@@ -1,0 +1,574 @@
+// vr_kernels.h — the integrator kernels (gfx950, wave64).
+//
+//   vr_track_kernel<INTEG, EXACT>  ratio tracking / delta tracking through the bricked grid
+//                                  (IntegratorRatioTracking.cpp:11-283, IntegratorDeltaTracking.cpp:11-176)
+//   vr_march_kernel<IMPROVED, EXACT> fixed-step marchers through a mesh-bounded medium
+//                                  (IntegratorHomogeneousRayMarcherNEE.cpp:10-118,
+//                                   IntegratorHomogeneousRayMarcherImproved.cpp:11-149)
+//   vr_resolve_kernel              per-pixel ordered sum over samples (BaseIntegrator.cpp:71,92,108)
+//
+// Work decomposition: one path sample (one castRay call) per lane.  Items are numbered
+// ((s * nrows + r) * width + x): the 64 lanes of a wave start on 64 neighbouring pixels of one
+// row for one sub-sample, so primary rays walk neighbouring voxels and the per-sample buffer
+// [s][r][x][rgb] is written in consecutive addresses.  Path lengths differ by orders of
+// magnitude (a background pixel ends at the bbox clip, a core pixel takes 10^4 steps), so the
+// tracking kernel is persistent: a lane whose path has ended takes the next item from a global
+// counter (one wave-aggregated atomic per refill) instead of idling until the wave's longest
+// path ends.  Every sample owns one slot of the staging buffer and vr_resolve_kernel sums the
+// slots of a pixel in sample order, so the image does not depend on which lane ran which path.
+#pragma once
+#include "vr_device.h"
+
+namespace vr {
+
+enum { INTEG_RATIO = 2, INTEG_DELTA = 3 };
+
+struct Counters {
+    unsigned long long path_samples, density_lookups, scatter_events, shadow_rays, ray_queries, step_limit_hits;
+};
+
+// Camera block: renderPartial's per-chunk constants + renderRay's per-pixel arithmetic
+// (BaseIntegrator.cpp:33-57, 287-312).  rot = the matrix Utils::rotate builds (Utils.cpp:34-53).
+struct CameraDev {
+    float    pos[3];
+    float    rot[9];
+    int32_t  has_rot;
+    float    scale, aspect, pixel_w, pixel_h;
+    uint32_t ref_w, ref_h;   // widthReference/heightReference (or width/height when 0)
+    uint32_t x0, y0;         // widthStartOffset, heightStartOffset
+    uint32_t width;          // columns rendered
+    uint32_t row_first, row_stride, nrows;
+    uint32_t spp, s_first, s_count;
+    const float2* offsets;   // assignPointToQuadrant(s, spp) for s < spp
+};
+
+struct WorkDev {
+    uint32_t           nitems;      // s_count * nrows * width
+    uint32_t*          counter;     // next item
+    float*             samples;     // [s_count][nrows][width][3]
+    Counters*          counters;
+    uint32_t           key0, key1;  // Philox key
+    uint32_t           step_limit;
+};
+
+struct TrackParams {
+    CameraDev cam;
+    WorkDev   work;
+    GridDev   density, temperature;
+    int32_t   has_temperature;
+    float     inv_mat[9], vec[3];
+    float     bmin[3], bmax1[3];     // float(bbox.min), float(bbox.max + 1)
+    float     sigma_a, sigma_s, sigma_maj;
+    float     t_min, t_max, step_mult;
+    float     light_mult, shadow_mult;
+    float     g;
+    float     light[3], light_color[3], emission[3], medium[3], background[3];
+    uint32_t  max_depth;
+};
+
+// primary ray of (abs column i, abs row j, sub-sample s)                  BaseIntegrator.cpp:35-64
+__device__ __forceinline__ f3 primary_direction(const CameraDev& c, uint32_t i, uint32_t j, uint32_t s)
+{
+    float x = (float)((2 * ((int)i + 0.5) / (float)c.ref_w - 1) * c.aspect * c.scale);
+    float y = (float)((1 - 2 * ((int)j + 0.5) / (float)c.ref_h) * c.scale);
+    f3 dn = normalize3(mk3(x, y, -1));
+    float2 off = c.offsets[s];
+    f3 d = mk3(dn.x + off.x * c.pixel_w, dn.y + off.y * c.pixel_h, dn.z + 0.0f);
+    if (c.has_rot) {
+        float px = d.x, py = d.y, pz = d.z;
+        d.x = c.rot[0] * px + c.rot[1] * py + c.rot[2] * pz;
+        d.y = c.rot[3] * px + c.rot[4] * py + c.rot[5] * pz;
+        d.z = c.rot[6] * px + c.rot[7] * py + c.rot[8] * pz;
+    }
+    return d;
+}
+
+__device__ __forceinline__ void store_sample(float* samples, uint32_t item, f3 c)
+{
+    float* o = samples + 3ull * item;
+    o[0] = c.x; o[1] = c.y; o[2] = c.z;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)v, o), hi = __shfl_xor((uint32_t)(v >> 32), o);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+
+// =============================================================================================
+// ratio / delta tracking
+// =============================================================================================
+#define VR_STEPS_PER_ROUND 32
+
+template <int INTEG, bool EXACT>
+__global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
+{
+    typedef Math<EXACT> M;
+    const int      lane = threadIdx.x & 63;
+    const uint32_t k0 = p.work.key0, k1 = p.work.key1;
+    const f3       light = mk3(p.light[0], p.light[1], p.light[2]);
+
+    // ---- per-lane path state (HandleIntersectionData, BaseIntegrator.h:21-50) ----
+    bool     alive = false, exhausted = false;
+    bool     shadow = false;            // walking directLightningRayMarch
+    uint32_t item = 0;
+    f3       eye = mk3(0, 0, 0), dir = mk3(0, 0, 1);   // current index-space ray (camera walk or shadow walk)
+    float    t = 0, t1 = 0, t0 = 0;     // tFar, iRay.t1(), iRay.t0()
+    f3       wdir = mk3(0, 0, 1);       // data->rayDirection
+    f3       radiance = mk3(0, 0, 0);   // data->radiance / result
+    float    T = 1.0f, Tsh = 1.0f;      // data->transmission, shadow-walk transmission
+    int      depth_remaining = 0;
+    f3       scatter_p = mk3(0, 0, 0);  // iRay(tFar) of the pending scatter event
+    float    scatter_len = 0;           // its pathLength
+    uint32_t saved_n = 0;
+    uint32_t steps = 0;
+    Rng        rng = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    VoxelCache vc = { 0xffffffffu, 0.0f }, vct = { 0xffffffffu, 0.0f };
+    unsigned long long n_lookups = 0;
+    uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0;
+
+    for (;;) {
+        // ---------------- refill: terminated lanes take the next items ----------------
+        for (;;) {
+            const bool               want = !alive && !exhausted;
+            const unsigned long long need = __ballot(want);
+            if (need == 0ull) break;
+            const int leader = __ffsll((long long)need) - 1;
+            uint32_t  base = 0;
+            if (lane == leader) base = atomicAdd(p.work.counter, (uint32_t)__popcll(need));
+            base = __shfl(base, leader);
+            if (want) {
+                const uint32_t mine = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (mine >= p.work.nitems) {
+                    exhausted = true;
+                } else {
+                    item = mine;
+                    const uint32_t x = mine % p.cam.width;
+                    const uint32_t q = mine / p.cam.width;
+                    const uint32_t r = q % p.cam.nrows;
+                    const uint32_t sl = q / p.cam.nrows;
+                    const uint32_t s = p.cam.s_first + sl;
+                    const uint32_t ci = p.cam.x0 + x;
+                    const uint32_t cj = p.cam.y0 + p.cam.row_first + r * p.cam.row_stride;
+                    n_paths++;
+                    // castRay prologue                      IntegratorRatioTracking.cpp:13-53
+                    wdir = primary_direction(p.cam, ci, cj, s);
+                    f3 weye = mk3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+                    // wRay.worldToIndexF(grid)               Ray.h:257-267, NanoVDB.h:2262-2270
+                    eye = mat_mult(p.inv_mat, mk3(weye.x - p.vec[0], weye.y - p.vec[1], weye.z - p.vec[2]));
+                    f3    idir = mat_mult(p.inv_mat, wdir);
+                    float length = sqrtf(idir.x * idir.x + idir.y * idir.y + idir.z * idir.z);
+                    float inv_length = 1.0f / length;
+                    dir = mk3(inv_length * idir.x, inv_length * idir.y, inv_length * idir.z);
+                    float c0 = length * 1e-5f, c1 = VR_FLT_MAX;
+                    if (!ray_clip(eye, dir, c0, c1, p.bmin, p.bmax1) || p.max_depth == 0) {
+                        // missed the grid (:37-39), or a zero scatter budget: the loop never runs (:55, :208)
+                        store_sample(p.work.samples, item, mk3(p.background[0], p.background[1], p.background[2]));
+                    } else {
+                        alive = true; shadow = false;
+                        t0 = c0; t1 = c1; t = c0;
+                        radiance = mk3(0, 0, 0);
+                        T = 1.0f;
+                        depth_remaining = (int)p.max_depth;
+                        steps = 0;
+                        rng.pixel = (cj << 16) | ci; rng.sample = s; rng.tag = 0; rng.n = 0;
+                        vc.idx = 0xffffffffu; vct.idx = 0xffffffffu;
+                    }
+                }
+            }
+        }
+        if (!__any(alive)) break;
+
+        // ---------------- a round of steps, no refill checks inside ----------------
+#pragma unroll 1
+        for (int it = 0; it < VR_STEPS_PER_ROUND; ++it) {
+            if (alive) {
+                bool  finished = false;      // path over: write `radiance`
+                bool  shadow_done = false;   // shadow walk over: resume the scatter event
+                float light_T = 1.0f;
+
+                if (++steps > p.work.step_limit) { n_limit++; finished = true; }
+
+                const bool in_shadow = (INTEG == INTEG_RATIO) && shadow;
+                if (!finished && !in_shadow && INTEG == INTEG_RATIO) {
+                    // Russian roulette on the camera walk     IntegratorRatioTracking.cpp:57-69
+                    if (T < 0.05f) {
+                        float q = 0.75f;
+                        if (rng_float(rng, k0, k1, 0.0f, 1.0f) < q) T = 0.0f;
+                        else T /= 1.0f - q;
+                    }
+                    if (T <= 0.0f) finished = true;
+                }
+
+                if (!finished) {
+                    // sigma = multiplier * acc.getValue(Coord::Floor(iRay(tFar)))            :71 / :238
+                    const float mult = in_shadow ? p.shadow_mult : p.light_mult;
+                    const float sigma = mult * grid_value(p.density, ray_at(eye, dir, t), vc);
+                    n_lookups++;
+                    const float mu_a = sigma * p.sigma_a;
+                    const float mu_s = sigma * p.sigma_s;
+                    const float mu_t = mu_a + mu_s;
+                    const float tmin = in_shadow ? p.t_min * 5 : p.t_min;                       // :216
+                    float len;
+                    if (sigma > 0.0f) {
+                        // free path: camera walk over the global majorant, shadow walk over mu_t   :80-82 / :247-249
+                        const float denom = in_shadow ? mu_t : p.sigma_maj;
+                        len = -M::log_(rng_float(rng, k0, k1, 0.00001f, 1.0f)) / denom;
+                        len *= p.step_mult;
+                        len = clamp_lo_hi(tmin, p.t_max, len);
+                    } else {
+                        len = in_shadow ? tmin * 100 : tmin * 10;                                // :252 / :85
+                    }
+                    t += len;                                                                 // :88 / :255
+                    if (t > t1) {                                                             // :91 / :258
+                        if (in_shadow) { shadow_done = true; light_T = Tsh; }
+                        else {
+                            // survivor: radiance + background * transmission                 :208 (delta :175)
+                            if (INTEG == INTEG_RATIO)
+                                radiance = add3(radiance, scale3(mk3(p.background[0], p.background[1], p.background[2]), T));
+                            else
+                                radiance = add3(radiance, mk3(p.background[0], p.background[1], p.background[2]));
+                            finished = true;
+                        }
+                    } else if (sigma > 0.0f) {
+                        const float att = M::exp_(-(len)*mu_t);                               // :103 / :266
+                        if (in_shadow) {
+                            Tsh *= att;                                                       // :269
+                            if (Tsh < 0.05f) {                                                // :272-279
+                                float q = 0.75f;
+                                if (rng_float(rng, k0, k1, 0.0f, 1.0f) < q) Tsh = 0.0f;
+                                else Tsh /= 1.0f - q;
+                            }
+                            if (Tsh <= 0.0f) { shadow_done = true; light_T = Tsh; }           // :281
+                        } else {
+                            const float pA = mu_a / p.sigma_maj;                              // :98-100
+                            const float pS = mu_s / p.sigma_maj;
+                            const float pn = 1 - pA - pS;
+                            const float pNull = (0 < pn) ? pn : 0;
+                            if (INTEG == INTEG_RATIO) T = T * att;                            // :105
+                            const float sample = rng_float(rng, k0, k1, 0.0f, 1.0f);          // :108
+                            if (INTEG == INTEG_RATIO && p.has_temperature) {                  // :110-122
+                                const float emission = grid_value(p.temperature, ray_at(eye, dir, t), vct);
+                                n_lookups++;
+                                if (emission > 0.0f) {
+                                    f3 e = scale3(mk3(p.emission[0], p.emission[1], p.emission[2]), T * mu_a);
+                                    e = scale3(e, emission);
+                                    e = scale3(e, len);
+                                    radiance = add3(radiance, e);
+                                }
+                            }
+                            if (sample < pNull) {
+                                // null collision
+                            } else if (sample < pNull + pA) {
+                                if (INTEG == INTEG_RATIO) {                                   // :127-131
+                                    radiance = add3(radiance, scale3(mk3(p.medium[0], p.medium[1], p.medium[2]), T));
+                                } else {                                                      // delta :101-113
+                                    if (p.has_temperature) {
+                                        (void)grid_value(p.temperature, ray_at(eye, dir, t), vct);
+                                        n_lookups++;
+                                        radiance = add3(radiance, scale3(mk3(p.emission[0], p.emission[1], p.emission[2]), mu_a));
+                                    }
+                                    radiance = add3(radiance, mk3(p.medium[0], p.medium[1], p.medium[2]));
+                                }
+                                finished = true;
+                            } else {
+                                // scattering                                                :133-191 (delta :115-158)
+                                depth_remaining--;                                            // :136 (the `< 0` test never fires)
+                                n_scatter++;
+                                if (INTEG == INTEG_DELTA) {
+                                    scatter_p = ray_at(eye, dir, t);
+                                    shadow_done = true;     // no shadow walk: go straight to the new direction
+                                } else if (T > 0.0f) {                                        // :141
+                                    // directLightningRayMarch prologue                       :213-234
+                                    n_shadow++;
+                                    scatter_p = ray_at(eye, dir, t);
+                                    scatter_len = len;
+                                    const f3 so = ray_at(eye, dir, t0);                       // :226 (segment START)
+                                    saved_n = rng.n;
+                                    rng.tag |= 0x80000000u; rng.n = 0;
+                                    float c0 = 1e-5f, c1 = VR_FLT_MAX;
+                                    if (!ray_clip(so, light, c0, c1, p.bmin, p.bmax1)) {      // :229-232
+                                        shadow_done = true; light_T = 1.0f;
+                                    } else {
+                                        shadow = true;
+                                        eye = so; dir = light; t = c0; t1 = c1; Tsh = 1.0f;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+
+                if (shadow_done && !finished) {
+                    if (INTEG == INTEG_RATIO) {
+                        // back on the camera stream
+                        rng.tag &= 0x7fffffffu; rng.n = saved_n;
+                        if (rng.n & 3u) rng_refill(rng, k0, k1);
+                        const float cos_theta = dot3(wdir, light);                            // :144
+                        const float hg = hg_phase(p.g, cos_theta);                            // :145
+                        f3 nee = scale3(mk3(p.light_color[0], p.light_color[1], p.light_color[2]), T * light_T); // :147-152
+                        nee = scale3(nee, scatter_len);
+                        nee = scale3(nee, hg);
+                        radiance = add3(radiance, nee);
+                    }
+                    const float xi1 = rng_float(rng, k0, k1, 0.0f, 0.9999f);
+                    const float xi2 = rng_float(rng, k0, k1, 0.0f, 0.9999f);
+                    const f3 scattered = hg_sample<EXACT>(p.g, wdir, xi1, xi2);               // :156-159
+                    wdir = scattered;                                                         // :178
+                    eye = scatter_p; dir = scattered;                                         // :179
+                    rng.tag += 1; rng.n = 0;
+                    shadow = false;
+                    float c0 = 1e-5f, c1 = VR_FLT_MAX;
+                    if (!ray_clip(eye, dir, c0, c1, p.bmin, p.bmax1)) {                       // :182-187 "scattering failed"
+                        finished = true;
+                    } else {
+                        t0 = c0; t1 = c1; t = c0;                                             // :189
+                        // `while (... && depthRemaining > 0)`: out of scatter budget, the walk ends as
+                        // escaped                                                            :55, :208 (delta :54, :175)
+                        if (depth_remaining <= 0) {
+                            const f3 bg = mk3(p.background[0], p.background[1], p.background[2]);
+                            radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, T) : bg);
+                            finished = true;
+                        }
+                    }
+                }
+
+                if (finished) {
+                    store_sample(p.work.samples, item, radiance);
+                    alive = false;
+                }
+            }
+        }
+    }
+
+    // ---- counters: one atomic per wave and counter ----
+    unsigned long long a = wave_sum(n_paths), b = wave_sum(n_lookups), c = wave_sum(n_scatter), d = wave_sum(n_shadow),
+                       e = wave_sum(n_limit);
+    if (lane == 0) {
+        atomicAdd(&p.work.counters->path_samples, a);
+        atomicAdd(&p.work.counters->density_lookups, b);
+        atomicAdd(&p.work.counters->scatter_events, c);
+        atomicAdd(&p.work.counters->shadow_rays, d);
+        if (e) atomicAdd(&p.work.counters->step_limit_hits, e);
+    }
+}
+
+// =============================================================================================
+// mesh-bounded fixed-step marchers
+// =============================================================================================
+
+// Threaded BVH in depth-first order: a node that is hit continues at node+1 (its first child, or
+// for a leaf the next subtree), a node that is missed continues at `skip`.  No stack.
+struct BvhNode {
+    float    lo[3], hi[3];
+    uint32_t skip;
+    uint32_t first, count;   // leaf: triangles [first, first+count); inner: count = 0
+};
+struct TriDev {
+    float    v0[3], e1[3], e2[3];
+    uint32_t prim;    // original primitive id (tie-break + prim_to_shape index)
+};
+struct MeshDev {
+    const BvhNode*  nodes;
+    const TriDev*   tris;
+    const uint32_t* prim_to_shape;
+    const float*    shape_dissolve;
+    uint32_t        nnodes;
+};
+struct MarchParams {
+    CameraDev cam;
+    WorkDev   work;
+    MeshDev   mesh;
+    float     sigma_a, sigma_s, g;
+    float     light[3], light_color[3], background[3];
+    uint32_t  max_depth;
+};
+
+// Moeller-Trumbore with the operation order of the oracle's tri_hit (stand-in for rtcIntersect1,
+// Utils/EmbreeHelper.cpp:4-36; tnear = 0, tfar = inf)
+__device__ __forceinline__ bool tri_hit(const TriDev& tr, f3 org, f3 dir, float& t_out)
+{
+    float px = dir.y * tr.e2[2] - dir.z * tr.e2[1];
+    float py = dir.z * tr.e2[0] - dir.x * tr.e2[2];
+    float pz = dir.x * tr.e2[1] - dir.y * tr.e2[0];
+    float det = tr.e1[0] * px + tr.e1[1] * py + tr.e1[2] * pz;
+    if (det == 0.0f) return false;
+    float inv = 1.0f / det;
+    float tx = org.x - tr.v0[0], ty = org.y - tr.v0[1], tz = org.z - tr.v0[2];
+    float u = (tx * px + ty * py + tz * pz) * inv;
+    if (u < 0.0f || u > 1.0f) return false;
+    float qx = ty * tr.e1[2] - tz * tr.e1[1];
+    float qy = tz * tr.e1[0] - tx * tr.e1[2];
+    float qz = tx * tr.e1[1] - ty * tr.e1[0];
+    float v = (dir.x * qx + dir.y * qy + dir.z * qz) * inv;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = (tr.e2[0] * qx + tr.e2[1] * qy + tr.e2[2] * qz) * inv;
+    if (!(t >= 0.0f)) return false;
+    t_out = t;
+    return true;
+}
+
+// closest hit; returns primitive id or -1
+__device__ __forceinline__ int closest_hit(const MeshDev& m, f3 org, f3 dir, float& t_out)
+{
+    const float ix = 1.0f / dir.x, iy = 1.0f / dir.y, iz = 1.0f / dir.z;
+    float    best_t = __builtin_huge_valf();
+    uint32_t best_prim = 0xffffffffu;
+    uint32_t n = 0;
+    while (n < m.nnodes) {
+        const BvhNode nd = m.nodes[n];
+        // slab test; fminf/fmaxf drop NaNs (0 * inf), which keeps the test conservative
+        float ax = (nd.lo[0] - org.x) * ix, bx = (nd.hi[0] - org.x) * ix;
+        float ay = (nd.lo[1] - org.y) * iy, by = (nd.hi[1] - org.y) * iy;
+        float az = (nd.lo[2] - org.z) * iz, bz = (nd.hi[2] - org.z) * iz;
+        float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+        float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_t));
+        if (tn <= tf) {
+            for (uint32_t k = 0; k < nd.count; ++k) {
+                const TriDev tr = m.tris[nd.first + k];
+                float        t;
+                if (tri_hit(tr, org, dir, t) && (t < best_t || (t == best_t && tr.prim < best_prim))) {
+                    best_t = t; best_prim = tr.prim;
+                }
+            }
+            n = n + 1;
+        } else {
+            n = nd.skip;
+        }
+    }
+    t_out = best_t;
+    return best_prim == 0xffffffffu ? -1 : (int)best_prim;
+}
+
+template <bool IMPROVED, bool EXACT>
+__global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
+{
+    typedef Math<EXACT> M;
+    const uint32_t k0 = p.work.key0, k1 = p.work.key1;
+    uint32_t n_queries = 0, n_light = 0, n_paths = 0;
+    for (uint32_t mine = blockIdx.x * blockDim.x + threadIdx.x; mine < p.work.nitems; mine += gridDim.x * blockDim.x) {
+        const uint32_t x = mine % p.cam.width;
+        const uint32_t q = mine / p.cam.width;
+        const uint32_t r = q % p.cam.nrows;
+        const uint32_t s = p.cam.s_first + q / p.cam.nrows;
+        const uint32_t ci = p.cam.x0 + x;
+        const uint32_t cj = p.cam.y0 + p.cam.row_first + r * p.cam.row_stride;
+        n_paths++;
+        Rng rng = { (cj << 16) | ci, s, 0, 0, 0, 0, 0, 0 };
+
+        f3  origin = mk3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+        f3  dir = primary_direction(p.cam, ci, cj, s);
+        int object_id = -1, previous_id = -1;                                  // BaseIntegrator.cpp:63
+        f3  result = mk3(0, 0, 0);
+        const f3 bg = mk3(p.background[0], p.background[1], p.background[2]);
+        uint32_t depth = 0;
+
+        // castRay + handleIntersection, recursion unrolled  IntegratorHomogeneousRayMarcherNEE.cpp:10-118
+        for (int guard = 0; guard < 4096; ++guard) {
+            if (depth >= p.max_depth) { result = mk3(0, 0, 0); break; }         // :12-14
+            float tfar;
+            n_queries++;
+            const int prim = closest_hit(p.mesh, origin, dir, tfar);            // :25
+            if (prim < 0) { result = bg; break; }                               // :44
+            previous_id = object_id;                                            // :30
+            object_id = (int)p.mesh.prim_to_shape[prim];                        // :33
+            const f3 hit_point = add3(scale3(dir, tfar), origin);               // :34
+            const float dissolve = p.mesh.shape_dissolve[object_id];            // :49
+            if (dissolve > 0) {                                                 // :52
+                if (previous_id == object_id) {                                 // :55 exit hit: march the segment
+                    float       transparency = 1;
+                    f3          acc = mk3(0, 0, 0);
+                    const float distance = tfar;                                // :59
+                    const f3    light_dir = mk3(p.light[0], p.light[1], p.light[2]);
+                    const f3    light_color = mk3(p.light_color[0], p.light_color[1], p.light_color[2]);
+                    const float density = 1.0f;                                 // Improved :69
+                    float       step_size = 0.2f;                               // :66-68
+                    const int   ns = (int)ceilf(distance / step_size);
+                    step_size = distance / ns;
+                    const f3 nd = normalize3(dir);                              // :70
+                    for (int n = 0; n < ns; n++) {                              // :73
+                        float tt;
+                        if (IMPROVED) {
+                            const double off = (double)rng_unit(rng, k0, k1);  // Improved :82-84
+                            tt = (float)(step_size * ((double)n + off));        // Improved :90
+                        } else {
+                            tt = step_size * ((float)n + 0.5f);                 // :75
+                        }
+                        const f3    sp = add3(origin, scale3(nd, tt));          // :76
+                        const float att = IMPROVED ? M::exp_(-step_size * density * (p.sigma_a + p.sigma_s))
+                                                   : M::exp_(-step_size * p.sigma_a); // :79
+                        transparency *= att;                                    // :82
+                        const f3 lo = add3(sp, scale3(light_dir, 0.001f));      // :84-85
+                        float    dl;
+                        n_queries++; n_light++;
+                        if (closest_hit(p.mesh, lo, light_dir, dl) >= 0) {      // :88
+                            if (IMPROVED) {
+                                const float cos_theta = dot3(nd, light_dir);    // Improved :107
+                                const float la = M::exp_(-dl * density * (p.sigma_a + p.sigma_s));
+                                f3 c = scale3(light_color, la);                 // Improved :110-117
+                                c = scale3(c, density);
+                                c = scale3(c, p.sigma_s);
+                                c = scale3(c, hg_phase(p.g, cos_theta));
+                                c = scale3(c, transparency);
+                                c = scale3(c, step_size);
+                                acc = add3(acc, c);
+                            } else {
+                                const float la = M::exp_(-dl * p.sigma_a);      // :91
+                                f3 c = scale3(light_color, transparency);       // :93-97
+                                c = scale3(c, la);
+                                c = scale3(c, step_size);
+                                acc = add3(acc, c);
+                            }
+                        }
+                        if (IMPROVED) {                                         // Improved :121-129
+                            if ((double)transparency < 1e-3) {
+                                if (rng_float(rng, k0, k1, 0, 1) > 1.f / 2) n = ns;
+                                else transparency *= 2;
+                            }
+                        }
+                    }
+                    result = add3(scale3(bg, transparency), acc);               // :102
+                    break;
+                }
+                origin = add3(hit_point, scale3(dir, 0.001f));                  // :105
+                continue;
+            }
+            if (previous_id == object_id) {                                     // :112-117
+                origin = add3(origin, scale3(dir, 0.001f));
+                depth += 1;
+                continue;
+            }
+            result = mk3(0, 0, 0);   // the reference falls off a non-void function here (:118): black
+            break;
+        }
+        store_sample(p.work.samples, mine, result);
+    }
+    unsigned long long a = wave_sum(n_paths), b = wave_sum(n_queries), c = wave_sum(n_light);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&p.work.counters->path_samples, a);
+        atomicAdd(&p.work.counters->ray_queries, b);
+        atomicAdd(&p.work.counters->shadow_rays, c);
+    }
+}
+
+// =============================================================================================
+// resolve: color += castRay(...) for s = 0..spp-1, then color / spp            BaseIntegrator.cpp:71,92,108
+// =============================================================================================
+// accum[pixel] carries the running sum across passes; the last pass divides.
+__global__ void __launch_bounds__(256) vr_resolve_kernel(const float* __restrict__ samples, float* __restrict__ accum,
+                                                         uint32_t npix, uint32_t s_count, int first_pass, int last_pass,
+                                                         float spp)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // one float channel per thread: coalesced
+    const uint32_t n = npix * 3u;
+    if (i >= n) return;
+    float c = first_pass ? 0.0f : accum[i];
+    for (uint32_t s = 0; s < s_count; ++s) c += samples[(size_t)s * n + i];
+    accum[i] = last_pass ? c / spp : c;
+}
+
+} // namespace vr
