@@ -36,6 +36,26 @@ class BackendError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.
+
+    libvr_backend.so needs `libamdhip64.so.7`.  The PyTorch wheel ships its own copy of that
+    soname; if both it and /opt/rocm's get loaded, the second one to initialise sees no GPU.
+    When torch is installed (bench.py and the multi-GPU scheduler use it for RCCL), load its copy
+    first so that the dynamic linker resolves our dependency to the same object.
+    Set VR_HIP_RUNTIME=system to skip this (stand-alone C/C++ hosts never need it).
+    """
+    if os.environ.get("VR_HIP_RUNTIME", "") == "system":
+        return
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libvr_backend.so; raises if it has not been built (see __graft_entry__.build)."""
     global _lib
@@ -44,6 +64,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `make -C volume_renderer_amd/csrc` "
                                 "(there is no CPU fallback)")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.vr_backend_create.argtypes = [C.c_int, C.POINTER(vp)]
