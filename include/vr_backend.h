@@ -31,7 +31,10 @@ enum {
     /* Same algorithm and random streams, hardware transcendentals (v_log_f32, v_exp_f32,
      * v_sin_f32, v_cos_f32) and empty-space stepping batched per zero-majorant cell: differs
      * from EXACT only by rounding.  The production mode. */
-    VR_MODE_FAST = 1
+    VR_MODE_FAST = 1,
+    /* EXACT arithmetic with FAST's batched empty-space stepping: must also be bit-identical to
+     * the oracle; exists so that tests can pin the batching on its own. */
+    VR_MODE_EXACT_SKIP = 2
 };
 
 /* ---- life cycle -------------------------------------------------------------------------

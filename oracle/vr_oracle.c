@@ -189,71 +189,116 @@ void vro_minstd_canonical_double(uint32_t* state, double* out)
     *out = ret;
 }
 
+/* Philox stream layout (the GPU path's; no reference counterpart):
+ *   counter = (pixel, sample, tag, step)   key = 64-bit seed
+ *   pixel = (row << 16) | column (absolute), tag = scatter count so far, | 0x80000000 inside the
+ *   shadow walk of that scatter event, | 0x40000000 for the direction sample of that event;
+ *   step = iteration index of the walk since the stream began.  One block per iteration:
+ *   word 0 = Russian roulette at the loop top, word 1 = free path, word 2 = collision type
+ *   (camera walk) or roulette (shadow walk).  A step's draws therefore do not depend on how many
+ *   draws earlier steps made, which lets the GPU take runs of empty-space steps at once.
+ * In VRO_RNG_REFERENCE mode every draw is the next RandomGenerator::getFloat of the chunk's
+ * mt19937, in the reference's call order. */
 typedef struct vro_rng {
     int      mode;
-    /* philox */
     uint32_t key[2];
-    uint32_t pixel, sample, tag, n;
-    uint32_t buf[4];
-    uint32_t saved_tag, saved_n;
-    /* reference-like */
+    uint32_t pixel, sample, tag, step, cur;
+    uint32_t blk[4];
+    int      blk_valid;
+    uint32_t saved_tag, saved_step;
     uint32_t* mt;         /* 625 words, owned by the row chunk */
     uint32_t* jitter;     /* minstd state, shared (the reference's function-static engine) */
 } vro_rng;
 
-static float rng_unit(vro_rng* g)
+static inline float unit24(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+
+static const uint32_t* rng_block(vro_rng* g)
 {
-    if ((g->n & 3u) == 0u) {
-        uint32_t ctr[4] = { g->pixel, g->sample, g->tag, g->n >> 2 };
-        vro_philox4x32_10(ctr, g->key, g->buf);
+    if (!g->blk_valid) {
+        uint32_t ctr[4] = { g->pixel, g->sample, g->tag, g->cur };
+        vro_philox4x32_10(ctr, g->key, g->blk);
+        g->blk_valid = 1;
     }
-    uint32_t w = g->buf[g->n & 3u];
-    g->n++;
-    return (float)(w >> 8) * (1.0f / 16777216.0f);
-}
-static float rng_get_float(vro_rng* g, float lo, float hi)
-{
-    if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, lo, hi);
-    return (rng_unit(g) * (hi - lo)) + lo;
+    return g->blk;
 }
 static void rng_begin_path(vro_rng* g, uint32_t i, uint32_t j, uint32_t s)
 {
     g->pixel = (j << 16) | i;
     g->sample = s;
     g->tag = 0;
-    g->n = 0;
+    g->step = 0;
+    g->blk_valid = 0;
+}
+/* top of every loop iteration of a walk */
+static void rng_begin_step(vro_rng* g)
+{
+    g->cur = g->step++;
+    g->blk_valid = 0;
+}
+/* getFloat(0, 1) of the roulette at the loop top (REF IntegratorRatioTracking.cpp:60) */
+static float rng_roulette(vro_rng* g)
+{
+    if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, 0.0f, 1.0f);
+    return (unit24(rng_block(g)[0]) * (1.0f - 0.0f)) + 0.0f;
+}
+/* getFloat(0.00001f, 1.0f) of the free-path sample (REF :80, :247) */
+static float rng_free_path(vro_rng* g)
+{
+    if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, 0.00001f, 1.0f);
+    return (unit24(rng_block(g)[1]) * (1.0f - 0.00001f)) + 0.00001f;
+}
+/* getFloat(0, 1) of the collision type (REF :108) / of the shadow walk's roulette (REF :275) */
+static float rng_event(vro_rng* g)
+{
+    if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, 0.0f, 1.0f);
+    return (unit24(rng_block(g)[2]) * (1.0f - 0.0f)) + 0.0f;
+}
+/* the two getFloat(0, 0.9999f) of sampleHenyeyGreenstein (REF Utils/DirectionSampler.cpp:43,58) */
+static void rng_direction(vro_rng* g, float* xi1, float* xi2)
+{
+    if (g->mode == VRO_RNG_REFERENCE) {
+        *xi1 = vro_reference_get_float(g->mt, 0.0f, 0.9999f);
+        *xi2 = vro_reference_get_float(g->mt, 0.0f, 0.9999f);
+        return;
+    }
+    uint32_t ctr[4] = { g->pixel, g->sample, g->tag | 0x40000000u, 0u }, w[4];
+    vro_philox4x32_10(ctr, g->key, w);
+    *xi1 = (unit24(w[0]) * (0.9999f - 0.0f)) + 0.0f;
+    *xi2 = (unit24(w[1]) * (0.9999f - 0.0f)) + 0.0f;
 }
 /* a new stream per scatter event ("bounce") */
 static void rng_next_bounce(vro_rng* g)
 {
-    if (g->mode == VRO_RNG_REFERENCE) return;
     g->tag += 1;
-    g->n = 0;
+    g->step = 0;
+    g->blk_valid = 0;
 }
-/* the shadow march of bounce b draws from stream (b | 0x80000000) */
+/* the shadow walk of bounce b draws from stream (b | 0x80000000) */
 static void rng_push_shadow(vro_rng* g)
 {
-    if (g->mode == VRO_RNG_REFERENCE) return;
     g->saved_tag = g->tag;
-    g->saved_n = g->n;
+    g->saved_step = g->step;
     g->tag |= 0x80000000u;
-    g->n = 0;
+    g->step = 0;
+    g->blk_valid = 0;
 }
 static void rng_pop_shadow(vro_rng* g)
 {
-    if (g->mode == VRO_RNG_REFERENCE) return;
     g->tag = g->saved_tag;
-    g->n = g->saved_n;
-    if (g->n & 3u) { /* refill the partially consumed block */
-        uint32_t ctr[4] = { g->pixel, g->sample, g->tag, g->n >> 2 };
-        vro_philox4x32_10(ctr, g->key, g->buf);
-    }
+    g->step = g->saved_step;
+    g->blk_valid = 0;
 }
-/* jitter of the Improved marcher: own engine in the reference, main stream under Philox */
-static double rng_jitter(vro_rng* g)
+/* Improved marcher, march step n: word 0 = jitter (own engine in the reference), word 1 = roulette */
+static double rng_march_jitter(vro_rng* g, uint32_t n)
 {
     if (g->mode == VRO_RNG_REFERENCE) { double d; vro_minstd_canonical_double(g->jitter, &d); return d; }
-    return (double)rng_unit(g);
+    g->cur = n; g->blk_valid = 0;
+    return (double)unit24(rng_block(g)[0]);
+}
+static float rng_march_roulette(vro_rng* g)
+{
+    if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, 0, 1);
+    return (unit24(rng_block(g)[1]) * (1.0f - 0.0f)) + 0.0f;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -758,6 +803,7 @@ static v3 cast_ray_delta(path_ctx* d)
 
     while (!terminated && depthRemaining > 0) {                             /* :54 */
         if (++steps > VRO_STEP_LIMIT) { d->st->step_limit_hits++; terminated = 1; break; }
+        rng_begin_step(d->rng);
         float sigma = densityMultiplier * grid_value(grid, ray_at(&iRay, tFar)); /* :55 */
         d->st->density_lookups++;
         float mu_a = sigma * o->sigma_a;
@@ -766,7 +812,7 @@ static v3 cast_ray_delta(path_ctx* d)
 
         float pathLength = 0;
         if (sigma > 0.0f) {                                                 /* :62-69 */
-            pathLength = -m_logf(rng_get_float(d->rng, 0.00001f, 1.0f)) / sigma_maj;
+            pathLength = -m_logf(rng_free_path(d->rng)) / sigma_maj;
             pathLength *= o->stepSizeMultiplier;
             pathLength = u_clamp(tMin, tMax, pathLength);
         } else {
@@ -784,7 +830,7 @@ static v3 cast_ray_delta(path_ctx* d)
         double sampleAttenuation = m_expf(-(pathLength)*mu_t);              /* :88 */
         d->rayPDF = (float)(d->rayPDF * (mu_t * sampleAttenuation));        /* :91 */
 
-        float sample = rng_get_float(d->rng, 0, 1);                         /* :93 */
+        float sample = rng_event(d->rng);                                   /* :93 */
         if (sample < pNull) {
             /* null collision */
         } else if (sample < pNull + pAbsorption) {                          /* :101-113 */
@@ -798,8 +844,8 @@ static v3 cast_ray_delta(path_ctx* d)
         } else {                                                            /* :115-158 */
             if (depthRemaining-- < 0) { terminated = 1; break; }            /* :118 */
             d->st->scatter_events++;
-            float xi1 = rng_get_float(d->rng, 0.0f, 0.9999f);
-            float xi2 = rng_get_float(d->rng, 0.0f, 0.9999f);
+            float xi1, xi2;
+            rng_direction(d->rng, &xi1, &xi2);
             v3 scattered = hg_sample(o->heyneyGreensteinG, d->rayDirection, xi1, xi2); /* :124-127 */
             v3 iRayOrigin = ray_at(&iRay, tFar);                            /* :130 */
             if (o->useImportanceSampling) {                                 /* :137-144 */
@@ -840,6 +886,7 @@ static float direct_lightning_ray_march(path_ctx* d, const iray* iRay)
 
     for (;;) {                                                              /* :236 */
         if (++steps > VRO_STEP_LIMIT) { d->st->step_limit_hits++; return transmission; }
+        rng_begin_step(d->rng);
         float sigma = densityMultiplier * grid_value(grid, ray_at(&lightRay, tFar)); /* :238 */
         d->st->density_lookups++;
         float mu_a = sigma * o->sigma_a;
@@ -847,7 +894,7 @@ static float direct_lightning_ray_march(path_ctx* d, const iray* iRay)
         float mu_t = mu_a + mu_s;
         float stepSize = 0;
         if (sigma > 0.0f) {                                                 /* :244-250 */
-            stepSize = -m_logf(rng_get_float(d->rng, 0.00001f, 1.0f)) / mu_t;
+            stepSize = -m_logf(rng_free_path(d->rng)) / mu_t;
             stepSize *= o->stepSizeMultiplier;
             stepSize = u_clamp(tMin, tMax, stepSize);
         } else {
@@ -860,7 +907,7 @@ static float direct_lightning_ray_march(path_ctx* d, const iray* iRay)
         transmission *= transmissionStep;                                   /* :269 */
         if (transmission < 0.05f) {                                         /* :272-279 */
             float q = 0.75f;
-            if (rng_get_float(d->rng, 0.0f, 1.0f) < q) transmission = 0.0f;
+            if (rng_event(d->rng) < q) transmission = 0.0f;
             else transmission /= 1.0f - q;
         }
         if (transmission <= 0.0f) return transmission;                      /* :281-282 */
@@ -890,9 +937,10 @@ static v3 cast_ray_ratio(path_ctx* d)
 
     while (!terminated && depthRemaining > 0) {                             /* :55 */
         if (++steps > VRO_STEP_LIMIT) { d->st->step_limit_hits++; terminated = 1; break; }
+        rng_begin_step(d->rng);
         if (transmission < 0.05f) {                                         /* :57-64 */
             float q = 0.75f;
-            if (rng_get_float(d->rng, 0.0f, 1.0f) < q) transmission = 0.0f;
+            if (rng_roulette(d->rng) < q) transmission = 0.0f;
             else transmission /= 1.0f - q;
         }
         if (transmission <= 0.0f) { terminated = 1; break; }                /* :66-69 */
@@ -905,7 +953,7 @@ static v3 cast_ray_ratio(path_ctx* d)
 
         float pathLength = 0;
         if (sigma > 0.0f) {                                                 /* :77-83 */
-            pathLength = -m_logf(rng_get_float(d->rng, 0.00001f, 1.0f)) / sigma_maj;
+            pathLength = -m_logf(rng_free_path(d->rng)) / sigma_maj;
             pathLength *= o->stepSizeMultiplier;
             pathLength = u_clamp(tMin, tMax, pathLength);
         } else {
@@ -924,7 +972,7 @@ static v3 cast_ray_ratio(path_ctx* d)
         transmission = (float)(transmission * sampleAttenuation);          /* :105 */
         d->rayPDF = (float)(d->rayPDF * (mu_t * sampleAttenuation));        /* :106 */
 
-        float sample = rng_get_float(d->rng, 0.0f, 1.0f);                   /* :108 */
+        float sample = rng_event(d->rng);                                   /* :108 */
 
         if (hasEmission) {                                                  /* :110-122 */
             float emission = grid_value(d->sc->temperature, ray_at(&iRay, tFar));
@@ -956,8 +1004,8 @@ static v3 cast_ray_ratio(path_ctx* d)
                 nee = v3_scale(nee, hgPDF);
                 radiance = v3_add(radiance, nee);
 
-                float xi1 = rng_get_float(d->rng, 0.0f, 0.9999f);
-                float xi2 = rng_get_float(d->rng, 0.0f, 0.9999f);
+                float xi1, xi2;
+                rng_direction(d->rng, &xi1, &xi2);
                 v3 scattered = hg_sample(o->heyneyGreensteinG, d->rayDirection, xi1, xi2); /* :156-159 */
                 v3 iRayOrigin = ray_at(&iRay, tFar);                        /* :162 */
                 if (o->useImportanceSampling) {                             /* :169-176 */
@@ -1022,7 +1070,7 @@ static v3 march_segment(path_ctx* d, int improved)
     for (size_t n = 0; n < (size_t)ns; n++) {                               /* NEE :73 */
         float t;
         if (improved) {
-            double randomOffset = rng_jitter(d->rng);                       /* Improved :82-84 */
+            double randomOffset = rng_march_jitter(d->rng, (uint32_t)n);      /* Improved :82-84 */
             t = (float)(step_size * (n + randomOffset));                    /* Improved :90 */
         } else {
             t = step_size * (n + 0.5f);                                     /* NEE :75 */
@@ -1059,7 +1107,7 @@ static v3 march_segment(path_ctx* d, int improved)
         if (improved) {                                                     /* Improved :121-129 */
             int dd = 2;
             if (transparency < 1e-3) {
-                if (rng_get_float(d->rng, 0, 1) > 1.f / dd) n = (size_t)ns;
+                if (rng_march_roulette(d->rng) > 1.f / dd) n = (size_t)ns;
                 else transparency *= dd;
             }
         }

@@ -10,7 +10,7 @@ import pytest
 
 import oracle_lib as ol
 import scenes
-from volume_renderer_amd import MODE_EXACT, MODE_FAST, Backend, Grid, copy_options
+from volume_renderer_amd import MODE_EXACT, MODE_EXACT_SKIP, MODE_FAST, Backend, Grid, copy_options
 
 pytestmark = pytest.mark.gpu
 
@@ -64,12 +64,14 @@ def test_upload_and_readback_ragged_grid(backend):
 
 @pytest.mark.parametrize("integ", [RATIO, DELTA])
 @pytest.mark.parametrize("regime", ["shipped", "textbook"])
-def test_tracking_exact_mode_is_bit_identical(backend, oracle, cloud64, integ, regime):
+@pytest.mark.parametrize("mode", [MODE_EXACT, MODE_EXACT_SKIP], ids=["exact", "exact_skip"])
+def test_tracking_exact_mode_is_bit_identical(backend, oracle, cloud64, integ, regime, mode):
+    """exact_skip takes runs of empty-space steps at once; image AND lookup count must not change."""
     o = scenes.options_cloud(integ, 64, 48, 40, 4, regime=regime)
     sc, _ = ol.make_scene(density=cloud64)
     want, wst = oracle_image(oracle, sc, o, integ)
     backend.set_density(cloud64)
-    backend.set_mode(MODE_EXACT)
+    backend.set_mode(mode)
     backend.set_seed(scenes.SEED)
     got = backend.render(o, integ)
     st = backend.last_stats()
@@ -85,7 +87,7 @@ def test_tracking_exact_with_rotation_crop_and_temperature(backend, oracle, clou
                 bbox_min=(-20, -20, -20))
     sc, _ = ol.make_scene(density=cloud64, temperature=temp)
     backend.set_density(cloud64, temp)
-    backend.set_mode(MODE_EXACT)
+    backend.set_mode(MODE_EXACT_SKIP)
     backend.set_seed(scenes.SEED)
     for integ in (RATIO, DELTA):
         o = scenes.options_cloud(integ, 64, 32, 24, 4, regime="shipped", widthReference=96, heightReference=72,

@@ -498,7 +498,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
 
     HIP_TRY(b, hipMemsetAsync(b->d_counters, 0, sizeof(Counters), b->stream));
     b->passes_used = 0;
-    const bool exact = b->mode == VR_MODE_EXACT;
+    const bool exact = b->mode != VR_MODE_FAST;
 
     for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)per_pass) {
         const uint32_t sc = (uint32_t)std::min<uint64_t>(per_pass, spp - s0);
@@ -529,10 +529,14 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 p.medium[i] = o->mediumColor[i]; p.background[i] = o->backgroundColor[i];
             }
             p.max_depth = o->maxDepth;
-            void (*kern)(const TrackParams) =
-                integrator == VR_INTEGRATOR_RATIO_TRACKING
-                    ? (exact ? vr_track_kernel<INTEG_RATIO, true> : vr_track_kernel<INTEG_RATIO, false>)
-                    : (exact ? vr_track_kernel<INTEG_DELTA, true> : vr_track_kernel<INTEG_DELTA, false>);
+            p.majorant = b->d_major;
+            void (*kern)(const TrackParams);
+            const bool ratio = integrator == VR_INTEGRATOR_RATIO_TRACKING;
+            switch (b->mode) {
+            case VR_MODE_EXACT:      kern = ratio ? vr_track_kernel<INTEG_RATIO, true, false> : vr_track_kernel<INTEG_DELTA, true, false>; break;
+            case VR_MODE_EXACT_SKIP: kern = ratio ? vr_track_kernel<INTEG_RATIO, true, true> : vr_track_kernel<INTEG_DELTA, true, true>; break;
+            default:                 kern = ratio ? vr_track_kernel<INTEG_RATIO, false, true> : vr_track_kernel<INTEG_DELTA, false, true>; break;
+            }
             int per_cu = 4;
             rc = launch_cap(b, kern, p, per_cu);
             if (rc) return rc;
@@ -640,7 +644,7 @@ void vr_backend_destroy(vr_backend* b)
 int vr_backend_set_mode(vr_backend* b, int mode)
 {
     if (!b) return VR_ERR_INVALID_ARG;
-    if (mode != VR_MODE_EXACT && mode != VR_MODE_FAST) return fail(b, VR_ERR_INVALID_ARG, "unknown mode %d", mode);
+    if (mode != VR_MODE_EXACT && mode != VR_MODE_FAST && mode != VR_MODE_EXACT_SKIP) return fail(b, VR_ERR_INVALID_ARG, "unknown mode %d", mode);
     b->mode = mode;
     return VR_OK;
 }

@@ -50,55 +50,44 @@ struct Math<true> {
     static __device__ __forceinline__ float log_(float x) { return vrm_logf(x); }
     static __device__ __forceinline__ float exp_(float x) { return vrm_expf(x); }
     static __device__ __forceinline__ void sincos_(float x, float& s, float& c) { vrm_sincosf(x, s, c); }
+    static __device__ __forceinline__ float div_(float a, float b) { return a / b; }
 };
 template <>
 struct Math<false> {
     static __device__ __forceinline__ float log_(float x) { return __logf(x); }
     static __device__ __forceinline__ float exp_(float x) { return __expf(x); }
     static __device__ __forceinline__ void sincos_(float x, float& s, float& c) { s = __sinf(x); c = __cosf(x); }
+    static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 };
 
-// ---- Philox4x32-10 (Salmon et al. 2011), counter = (pixel, sample, stream tag, block) ---------
+// ---- Philox4x32-10 (Salmon et al. 2011) ------------------------------------------------------
 // Replaces RandomGenerator (Utils/RandomGenerator.cpp:4-14): only the ranges of its draws are
-// contract.  pixel = (row << 16) | column in absolute image coordinates, so a pixel's stream does
-// not depend on crop, row partition or GPU count; tag = scatter count, | 0x80000000 for the
-// shadow march of that scatter event.
-struct Rng {
-    uint32_t pixel, sample, tag, n;
-    uint32_t b0, b1, b2, b3;
-};
+// contract.  Stream layout (mirrored by the oracle's vro_rng):
+//   counter = (pixel, sample, tag, step), key = 64-bit seed
+//   pixel = (row << 16) | column in absolute image coordinates, so a pixel's stream does not depend
+//   on crop, row partition or GPU count; tag = scatter count so far, | 0x80000000 inside the shadow
+//   walk of that scatter event, | 0x40000000 for its direction sample; step = iteration index of
+//   the walk.  ONE block per iteration: word 0 = roulette at the loop top, word 1 = free path,
+//   word 2 = collision type (camera walk) / roulette (shadow walk).
+// A step's draws do not depend on how many draws earlier steps made: every lane of a wave
+// generates its block at the same instruction, and runs of empty-space steps can be taken at once.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = h1 ^ c1 ^ k0;
-        uint32_t n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
-__device__ __forceinline__ void rng_refill(Rng& g, uint32_t k0, uint32_t k1)
-{
-    philox4x32_10(g.pixel, g.sample, g.tag, g.n >> 2, k0, k1, g.b0, g.b1, g.b2, g.b3);
-}
-// next uniform in [0,1) with 24 bits
-__device__ __forceinline__ float rng_unit(Rng& g, uint32_t k0, uint32_t k1)
-{
-    uint32_t sel = g.n & 3u;
-    if (sel == 0u) rng_refill(g, k0, k1);
-    uint32_t w = sel == 0u ? g.b0 : (sel == 1u ? g.b1 : (sel == 2u ? g.b2 : g.b3));
-    g.n++;
-    return (float)(w >> 8) * (1.0f / 16777216.0f);
-}
-// RandomGenerator::getFloat(min, max): a + u*(b-a)
-__device__ __forceinline__ float rng_float(Rng& g, uint32_t k0, uint32_t k1, float lo, float hi)
-{
-    return (rng_unit(g, k0, k1) * (hi - lo)) + lo;
-}
+// uniform in [0,1) with 24 bits, then RandomGenerator::getFloat(lo, hi) = lo + u*(hi-lo)
+__device__ __forceinline__ float unit24(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float in_range(uint32_t w, float lo, float hi) { return (unit24(w) * (hi - lo)) + lo; }
 
 // ---- nanovdb::Ray<float> ----------------------------------------------------------------------
 struct Ray {
@@ -173,6 +162,71 @@ __device__ __forceinline__ float grid_value(const GridDev& g, f3 p, VoxelCache& 
     }
     return c.val;
 }
+// same lookup, also reporting the voxel (relative to bbox.min) it fell into
+__device__ __forceinline__ float grid_fetch(const GridDev& g, f3 p, VoxelCache& c, int32_t& i, int32_t& j, int32_t& k,
+                                            bool& inside)
+{
+    i = (int32_t)floorf(p.x) - g.min[0];
+    j = (int32_t)floorf(p.y) - g.min[1];
+    k = (int32_t)floorf(p.z) - g.min[2];
+    inside = (uint32_t)i < (uint32_t)g.dim[0] && (uint32_t)j < (uint32_t)g.dim[1] && (uint32_t)k < (uint32_t)g.dim[2];
+    if (!inside) return g.background;
+    uint32_t off = brick_offset(g, (uint32_t)i, (uint32_t)j, (uint32_t)k);
+    if (off != c.idx) {
+        c.val = g.bricks[off];
+        c.idx = off;
+    }
+    return c.val;
+}
+
+// ---- runs of empty-space steps ---------------------------------------------------------------
+// In a voxel with sigma <= 0 the reference's walks only do `tFar += step` with a constant step and
+// no random draw (IntegratorRatioTracking.cpp:84-96, :251-263; IntegratorDeltaTracking.cpp:70-82).
+// empty_run returns how many of those iterations (k >= 1) can be taken at once while every lookup
+// position stays inside the box [lo, lo+size)^3 — the current voxel, or its whole 8^3 brick when
+// the brick's majorant says it is empty — and every new t stays <= t1, and advances t exactly as k
+// sequential float additions would:  inside one binade [2^e, 2^(e+1)) a float is m * 2^(e-23)
+// with integer m, and fl(t + step) = t + q * 2^(e-23) with q = step / 2^(e-23) rounded to nearest
+// (ties are not handled here: they fall back to a single step), so k additions add k*q to the
+// integer bit pattern of t.  The box is shrunk by `slack` on every side, which covers the rounding
+// of fmaf(t, dir, eye) and of the exit-distance estimate; estimates only ever make k smaller.
+__device__ __forceinline__ uint32_t empty_run(f3 eye, f3 dir, float& t, float t1, float step, float lox, float loy,
+                                              float loz, float size)
+{
+    const float slack = 0.01f;
+    const float px = dir.x > 0 ? lox + size - slack : lox + slack;
+    const float py = dir.y > 0 ? loy + size - slack : loy + slack;
+    const float pz = dir.z > 0 ? loz + size - slack : loz + slack;
+    const float tx = dir.x != 0 ? (px - eye.x) * __builtin_amdgcn_rcpf(dir.x) : VR_FLT_MAX;
+    const float ty = dir.y != 0 ? (py - eye.y) * __builtin_amdgcn_rcpf(dir.y) : VR_FLT_MAX;
+    const float tz = dir.z != 0 ? (pz - eye.z) * __builtin_amdgcn_rcpf(dir.z) : VR_FLT_MAX;
+    const float t_safe = fminf(fminf(tx, ty), fminf(tz, t1));
+    const uint32_t tb = __float_as_uint(t);
+    const uint32_t et = tb >> 23;                                  // t > 0: sign bit clear
+    uint32_t k = 1;
+    if (t_safe > t && et >= 24u && et < 254u) {
+        const float x = step * __uint_as_float((277u - et) << 23); // step / ulp(t), exact
+        const float xf = floorf(x);
+        const float fr = x - xf;
+        if (x >= 1.0f && x < 4194304.0f && fr != 0.5f) {
+            const float qf = fr > 0.5f ? xf + 1.0f : xf;
+            const float qu = qf * __uint_as_float((et - 23u) << 23);   // q * ulp(t), exact
+            const float rq = __builtin_amdgcn_rcpf(qf);
+            // steps until the box / ray end, and until the mantissa would leave the binade
+            const float k1 = floorf((t_safe - t) * __builtin_amdgcn_rcpf(qu) * 0.999999f) - 1.0f;
+            const float k2 = floorf((float)(0x7fffffu - (tb & 0x7fffffu)) * rq * 0.999999f) - 1.0f;
+            const float kf = fminf(fminf(k1, k2), 65536.0f);
+            if (kf >= 2.0f) {
+                k = (uint32_t)kf;
+                t = __uint_as_float(tb + k * (uint32_t)qf);
+                return k;
+            }
+        }
+    }
+    t += step;
+    return 1;
+}
+
 __device__ __forceinline__ float grid_value_nocache(const GridDev& g, f3 p)
 {
     int32_t i = (int32_t)floorf(p.x) - g.min[0];

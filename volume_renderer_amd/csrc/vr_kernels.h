@@ -55,6 +55,7 @@ struct TrackParams {
     CameraDev cam;
     WorkDev   work;
     GridDev   density, temperature;
+    const float* majorant;           // per-brick max of the density grid
     int32_t   has_temperature;
     float     inv_mat[9], vec[3];
     float     bmin[3], bmax1[3];     // float(bbox.min), float(bbox.max + 1)
@@ -104,7 +105,9 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 // =============================================================================================
 #define VR_STEPS_PER_ROUND 32
 
-template <int INTEG, bool EXACT>
+// SKIP: take runs of empty-space iterations at once (empty_run, vr_device.h) — same results bit
+// for bit, fewer trips through the loop.
+template <int INTEG, bool EXACT, bool SKIP>
 __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
 {
     typedef Math<EXACT> M;
@@ -124,10 +127,11 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
     int      depth_remaining = 0;
     f3       scatter_p = mk3(0, 0, 0);  // iRay(tFar) of the pending scatter event
     float    scatter_len = 0;           // its pathLength
-    uint32_t saved_n = 0;
     uint32_t steps = 0;
-    Rng        rng = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    uint32_t rng_pixel = 0, rng_sample = 0, rng_tag = 0, rng_step = 0;   // Philox counter (vr_device.h)
     VoxelCache vc = { 0xffffffffu, 0.0f }, vct = { 0xffffffffu, 0.0f };
+    uint32_t   brick_id = 0xffffffffu;  // one-entry cache of "this brick's majorant is <= 0"
+    bool       brick_empty = false;
     unsigned long long n_lookups = 0;
     uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0;
 
@@ -175,7 +179,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                         T = 1.0f;
                         depth_remaining = (int)p.max_depth;
                         steps = 0;
-                        rng.pixel = (cj << 16) | ci; rng.sample = s; rng.tag = 0; rng.n = 0;
+                        rng_pixel = (cj << 16) | ci; rng_sample = s; rng_tag = 0; rng_step = 0;
                         vc.idx = 0xffffffffu; vct.idx = 0xffffffffu;
                     }
                 }
@@ -190,67 +194,82 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                 bool  finished = false;      // path over: write `radiance`
                 bool  shadow_done = false;   // shadow walk over: resume the scatter event
                 float light_T = 1.0f;
-
-                if (++steps > p.work.step_limit) { n_limit++; finished = true; }
-
                 const bool in_shadow = (INTEG == INTEG_RATIO) && shadow;
-                if (!finished && !in_shadow && INTEG == INTEG_RATIO) {
+
+                // sigma = multiplier * acc.getValue(Coord::Floor(iRay(tFar)))                :71 / :238
+                // (looked up ahead of the roulette so that the wave generates its random block once;
+                //  a path the roulette ends does not count the lookup, as in the reference)
+                int32_t     vi, vj, vk;
+                bool        inside;
+                const float mult = in_shadow ? p.shadow_mult : p.light_mult;
+                const float sigma = mult * grid_fetch(p.density, ray_at(eye, dir, t), vc, vi, vj, vk, inside);
+                const bool  roulette = INTEG == INTEG_RATIO && !in_shadow && T < 0.05f;
+                uint32_t    w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+                if (sigma > 0.0f || roulette) philox4x32_10(rng_pixel, rng_sample, rng_tag, rng_step, k0, k1, w0, w1, w2, w3);
+
+                if (steps > p.work.step_limit) { n_limit++; finished = true; }
+                if (roulette) {
                     // Russian roulette on the camera walk     IntegratorRatioTracking.cpp:57-69
-                    if (T < 0.05f) {
-                        float q = 0.75f;
-                        if (rng_float(rng, k0, k1, 0.0f, 1.0f) < q) T = 0.0f;
-                        else T /= 1.0f - q;
-                    }
+                    const float q = 0.75f;
+                    if (in_range(w0, 0.0f, 1.0f) < q) T = 0.0f;
+                    else T /= 1.0f - q;
                     if (T <= 0.0f) finished = true;
                 }
 
                 if (!finished) {
-                    // sigma = multiplier * acc.getValue(Coord::Floor(iRay(tFar)))            :71 / :238
-                    const float mult = in_shadow ? p.shadow_mult : p.light_mult;
-                    const float sigma = mult * grid_value(p.density, ray_at(eye, dir, t), vc);
-                    n_lookups++;
                     const float mu_a = sigma * p.sigma_a;
                     const float mu_s = sigma * p.sigma_s;
                     const float mu_t = mu_a + mu_s;
                     const float tmin = in_shadow ? p.t_min * 5 : p.t_min;                       // :216
-                    float len;
+                    float    len;
+                    uint32_t krun = 1;
                     if (sigma > 0.0f) {
                         // free path: camera walk over the global majorant, shadow walk over mu_t   :80-82 / :247-249
                         const float denom = in_shadow ? mu_t : p.sigma_maj;
-                        len = -M::log_(rng_float(rng, k0, k1, 0.00001f, 1.0f)) / denom;
+                        len = M::div_(-M::log_(in_range(w1, 0.00001f, 1.0f)), denom);
                         len *= p.step_mult;
                         len = clamp_lo_hi(tmin, p.t_max, len);
+                        t += len;                                                             // :88 / :255
                     } else {
-                        len = in_shadow ? tmin * 100 : tmin * 10;                                // :252 / :85
+                        len = in_shadow ? tmin * 100 : tmin * 10;                             // :252 / :85
+                        if (SKIP && inside) {
+                            const uint32_t bid = vc.idx >> 9;
+                            if (bid != brick_id) { brick_id = bid; brick_empty = p.majorant[bid] <= 0.0f && mult >= 0.0f; }
+                            const int32_t m = brick_empty ? ~7 : ~0;
+                            krun = empty_run(eye, dir, t, t1, len, (float)(p.density.min[0] + (vi & m)),
+                                             (float)(p.density.min[1] + (vj & m)), (float)(p.density.min[2] + (vk & m)),
+                                             brick_empty ? 8.0f : 1.0f);
+                        } else {
+                            t += len;
+                        }
                     }
-                    t += len;                                                                 // :88 / :255
+                    n_lookups += krun;
+                    rng_step += krun;
+                    steps += krun;
                     if (t > t1) {                                                             // :91 / :258
                         if (in_shadow) { shadow_done = true; light_T = Tsh; }
                         else {
                             // survivor: radiance + background * transmission                 :208 (delta :175)
-                            if (INTEG == INTEG_RATIO)
-                                radiance = add3(radiance, scale3(mk3(p.background[0], p.background[1], p.background[2]), T));
-                            else
-                                radiance = add3(radiance, mk3(p.background[0], p.background[1], p.background[2]));
+                            const f3 bg = mk3(p.background[0], p.background[1], p.background[2]);
+                            radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, T) : bg);
                             finished = true;
                         }
                     } else if (sigma > 0.0f) {
-                        const float att = M::exp_(-(len)*mu_t);                               // :103 / :266
                         if (in_shadow) {
-                            Tsh *= att;                                                       // :269
+                            Tsh *= M::exp_(-(len)*mu_t);                                      // :266-269
                             if (Tsh < 0.05f) {                                                // :272-279
-                                float q = 0.75f;
-                                if (rng_float(rng, k0, k1, 0.0f, 1.0f) < q) Tsh = 0.0f;
+                                const float q = 0.75f;
+                                if (in_range(w2, 0.0f, 1.0f) < q) Tsh = 0.0f;
                                 else Tsh /= 1.0f - q;
                             }
                             if (Tsh <= 0.0f) { shadow_done = true; light_T = Tsh; }           // :281
                         } else {
-                            const float pA = mu_a / p.sigma_maj;                              // :98-100
-                            const float pS = mu_s / p.sigma_maj;
+                            const float pA = M::div_(mu_a, p.sigma_maj);                      // :98-100
+                            const float pS = M::div_(mu_s, p.sigma_maj);
                             const float pn = 1 - pA - pS;
                             const float pNull = (0 < pn) ? pn : 0;
-                            if (INTEG == INTEG_RATIO) T = T * att;                            // :105
-                            const float sample = rng_float(rng, k0, k1, 0.0f, 1.0f);          // :108
+                            if (INTEG == INTEG_RATIO) T = T * M::exp_(-(len)*mu_t);           // :103-105
+                            const float sample = in_range(w2, 0.0f, 1.0f);                    // :108
                             if (INTEG == INTEG_RATIO && p.has_temperature) {                  // :110-122
                                 const float emission = grid_value(p.temperature, ray_at(eye, dir, t), vct);
                                 n_lookups++;
@@ -288,8 +307,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                                     scatter_p = ray_at(eye, dir, t);
                                     scatter_len = len;
                                     const f3 so = ray_at(eye, dir, t0);                       // :226 (segment START)
-                                    saved_n = rng.n;
-                                    rng.tag |= 0x80000000u; rng.n = 0;
+                                    rng_tag |= 0x80000000u; rng_step = 0;
                                     float c0 = 1e-5f, c1 = VR_FLT_MAX;
                                     if (!ray_clip(so, light, c0, c1, p.bmin, p.bmax1)) {      // :229-232
                                         shadow_done = true; light_T = 1.0f;
@@ -305,9 +323,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
 
                 if (shadow_done && !finished) {
                     if (INTEG == INTEG_RATIO) {
-                        // back on the camera stream
-                        rng.tag &= 0x7fffffffu; rng.n = saved_n;
-                        if (rng.n & 3u) rng_refill(rng, k0, k1);
+                        rng_tag &= 0x7fffffffu;   // back on the camera stream
                         const float cos_theta = dot3(wdir, light);                            // :144
                         const float hg = hg_phase(p.g, cos_theta);                            // :145
                         f3 nee = scale3(mk3(p.light_color[0], p.light_color[1], p.light_color[2]), T * light_T); // :147-152
@@ -315,12 +331,14 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                         nee = scale3(nee, hg);
                         radiance = add3(radiance, nee);
                     }
-                    const float xi1 = rng_float(rng, k0, k1, 0.0f, 0.9999f);
-                    const float xi2 = rng_float(rng, k0, k1, 0.0f, 0.9999f);
+                    uint32_t h0, h1, h2, h3;
+                    philox4x32_10(rng_pixel, rng_sample, rng_tag | 0x40000000u, 0u, k0, k1, h0, h1, h2, h3);
+                    const float xi1 = in_range(h0, 0.0f, 0.9999f);
+                    const float xi2 = in_range(h1, 0.0f, 0.9999f);
                     const f3 scattered = hg_sample<EXACT>(p.g, wdir, xi1, xi2);               // :156-159
                     wdir = scattered;                                                         // :178
                     eye = scatter_p; dir = scattered;                                         // :179
-                    rng.tag += 1; rng.n = 0;
+                    rng_tag += 1; rng_step = 0;
                     shadow = false;
                     float c0 = 1e-5f, c1 = VR_FLT_MAX;
                     if (!ray_clip(eye, dir, c0, c1, p.bmin, p.bmax1)) {                       // :182-187 "scattering failed"
@@ -458,7 +476,7 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
         const uint32_t ci = p.cam.x0 + x;
         const uint32_t cj = p.cam.y0 + p.cam.row_first + r * p.cam.row_stride;
         n_paths++;
-        Rng rng = { (cj << 16) | ci, s, 0, 0, 0, 0, 0, 0 };
+        const uint32_t rng_pixel = (cj << 16) | ci;
 
         f3  origin = mk3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
         f3  dir = primary_direction(p.cam, ci, cj, s);
@@ -492,8 +510,10 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
                     const f3 nd = normalize3(dir);                              // :70
                     for (int n = 0; n < ns; n++) {                              // :73
                         float tt;
+                        uint32_t w0 = 0, w1 = 0, w2, w3;   // one Philox block per march step: jitter, roulette
                         if (IMPROVED) {
-                            const double off = (double)rng_unit(rng, k0, k1);  // Improved :82-84
+                            philox4x32_10(rng_pixel, s, 0u, (uint32_t)n, k0, k1, w0, w1, w2, w3);
+                            const double off = (double)unit24(w0);              // Improved :82-84
                             tt = (float)(step_size * ((double)n + off));        // Improved :90
                         } else {
                             tt = step_size * ((float)n + 0.5f);                 // :75
@@ -526,7 +546,7 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
                         }
                         if (IMPROVED) {                                         // Improved :121-129
                             if ((double)transparency < 1e-3) {
-                                if (rng_float(rng, k0, k1, 0, 1) > 1.f / 2) n = ns;
+                                if (in_range(w1, 0, 1) > 1.f / 2) n = ns;
                                 else transparency *= 2;
                             }
                         }
