@@ -221,6 +221,8 @@ struct vr_backend {
     Counters* d_counters = nullptr;
     int*      d_maxbits = nullptr;
 
+    TrackCold*             d_cold = nullptr;
+    std::vector<TrackCold> cold_host;
     std::vector<Pass> passes;
     size_t            passes_used = 0;
     vr_render_stats   stats{};
@@ -420,6 +422,21 @@ float ulp_of(float v)
     return std::nextafter(v, INFINITY) - v;
 }
 
+// upper estimate of the ray parameter t (index units) any walk of this frame can reach
+float tracking_t_max(const vr_backend* b, const vr_options_pod* o)
+{
+    float diag = 0.0f, dist = 0.0f;
+    for (int i = 0; i < 3; ++i) {
+        const float ext = b->bmax1[i] - b->bmin[i];
+        diag += ext * ext;
+        float e = 0.0f;
+        for (int k = 0; k < 3; ++k) e += b->inv_mat[3 * i + k] * (o->cameraPosition[k] - b->vec[k]);
+        const float c = 0.5f * (b->bmax1[i] + b->bmin[i]);
+        dist += (e - c) * (e - c);
+    }
+    return std::sqrt(dist) + 2.0f * std::sqrt(diag);
+}
+
 int validate(vr_backend* b, const vr_options_pod* o, int integrator)
 {
     if (!o) return fail(b, VR_ERR_INVALID_ARG, "options == NULL");
@@ -434,16 +451,9 @@ int validate(vr_backend* b, const vr_options_pod* o, int integrator)
         // every step must advance t in float, or the reference's loops never end
         if (!(o->stepSizeMin > 0.0f) || !(o->stepSizeMax >= o->stepSizeMin))
             return fail(b, VR_ERR_INVALID_ARG, "stepSize min must be > 0 and <= max (the reference would not terminate)");
-        float diag = 0.0f, dist = 0.0f;
-        for (int i = 0; i < 3; ++i) {
-            const float ext = b->bmax1[i] - b->bmin[i];
-            diag += ext * ext;
-            float e = 0.0f;
-            for (int k = 0; k < 3; ++k) e += b->inv_mat[3 * i + k] * (o->cameraPosition[k] - b->vec[k]);
-            const float c = 0.5f * (b->bmax1[i] + b->bmin[i]);
-            dist += (e - c) * (e - c);
-        }
-        const float tmax = std::sqrt(dist) + 2.0f * std::sqrt(diag);
+        const float tmax = tracking_t_max(b, o);
+        float diag = 0.0f;
+        for (int i = 0; i < 3; ++i) diag += (b->bmax1[i] - b->bmin[i]) * (b->bmax1[i] - b->bmin[i]);
         if (o->stepSizeMin < ulp_of(tmax))
             return fail(b, VR_ERR_INVALID_ARG, "stepSize min %g is below float resolution at ray parameter %g", o->stepSizeMin, tmax);
         if (std::sqrt(diag) / o->stepSizeMin > 1.0e8f)
@@ -491,6 +501,12 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
     rc = ensure(b, b->d_samples, b->samples_cap, (size_t)(npix * per_pass * 3));
     if (rc) return rc;
 
+    // the voxel-span / empty-run estimates assume ray parameters of at most a few thousand voxels
+    bool span_ok = true;
+    if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) span_ok = tracking_t_max(b, o) < 8000.0f;
+    b->cold_host.clear();
+    b->cold_host.reserve(spp + 1);
+
     WorkDev work{};
     work.counter = b->d_work; work.samples = b->d_samples; work.counters = b->d_counters;
     work.key0 = (uint32_t)b->seed; work.key1 = (uint32_t)(b->seed >> 32);
@@ -514,25 +530,36 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
         HIP_TRY(b, hipMemsetAsync(b->d_work, 0, sizeof(uint32_t), b->stream));
 
         if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
+            TrackCold cold{};
+            cold.cam = cam;
+            memcpy(cold.inv_mat, b->inv_mat, sizeof cold.inv_mat); memcpy(cold.vec, b->vec, sizeof cold.vec);
+            memcpy(cold.bmin, b->bmin, sizeof cold.bmin); memcpy(cold.bmax1, b->bmax1, sizeof cold.bmax1);
+            cold.g = o->heyneyGreensteinG;
+            for (int i = 0; i < 3; ++i) { cold.light[i] = o->lightPosition[i]; cold.light_color[i] = o->lightColor[i]; }
+            cold.max_depth = o->maxDepth;
+            b->cold_host.push_back(cold);    // stays alive until the stream has consumed the copy
+            HIP_TRY(b, hipMemcpyAsync(b->d_cold, &b->cold_host.back(), sizeof(TrackCold), hipMemcpyHostToDevice, b->stream));
             TrackParams p{};
-            p.cam = cam; p.work = work;
+            p.cold = b->d_cold; p.work = work;
             p.density = b->grid; p.temperature = b->tgrid; p.has_temperature = b->has_temperature ? 1 : 0;
-            memcpy(p.inv_mat, b->inv_mat, sizeof p.inv_mat); memcpy(p.vec, b->vec, sizeof p.vec);
-            memcpy(p.bmin, b->bmin, sizeof p.bmin); memcpy(p.bmax1, b->bmax1, sizeof p.bmax1);
             p.sigma_a = o->sigma_a; p.sigma_s = o->sigma_s;
             p.sigma_maj = b->max_value * (o->sigma_a + o->sigma_s);          // IntegratorRatioTracking.cpp:42-45
             p.t_min = o->stepSizeMin; p.t_max = o->stepSizeMax; p.step_mult = o->stepSizeMultiplier;
             p.light_mult = o->lightRayDensityMultiplier; p.shadow_mult = o->shadowRayDensityMultiplier;
-            p.g = o->heyneyGreensteinG;
             for (int i = 0; i < 3; ++i) {
-                p.light[i] = o->lightPosition[i]; p.light_color[i] = o->lightColor[i]; p.emission[i] = o->emissionColor[i];
-                p.medium[i] = o->mediumColor[i]; p.background[i] = o->backgroundColor[i];
+                p.emission[i] = o->emissionColor[i]; p.medium[i] = o->mediumColor[i]; p.background[i] = o->backgroundColor[i];
             }
-            p.max_depth = o->maxDepth;
+            // typical free path (index units) well under a voxel: remember each voxel's t-interval
+            {
+                const float mean_free = p.sigma_maj > 0.0f ? o->stepSizeMultiplier / p.sigma_maj : 1e30f;
+                const float typical = std::min(std::max(o->stepSizeMin, mean_free), o->stepSizeMax);
+                p.use_span = (typical < 0.25f && span_ok) ? 1 : 0;
+            }
             p.majorant = b->d_major;
             void (*kern)(const TrackParams);
             const bool ratio = integrator == VR_INTEGRATOR_RATIO_TRACKING;
-            switch (b->mode) {
+            switch (span_ok ? b->mode : (b->mode == VR_MODE_FAST ? -1 : VR_MODE_EXACT)) {
+            case -1:                 kern = ratio ? vr_track_kernel<INTEG_RATIO, false, false> : vr_track_kernel<INTEG_DELTA, false, false>; break;
             case VR_MODE_EXACT:      kern = ratio ? vr_track_kernel<INTEG_RATIO, true, false> : vr_track_kernel<INTEG_DELTA, true, false>; break;
             case VR_MODE_EXACT_SKIP: kern = ratio ? vr_track_kernel<INTEG_RATIO, true, true> : vr_track_kernel<INTEG_DELTA, true, true>; break;
             default:                 kern = ratio ? vr_track_kernel<INTEG_RATIO, false, true> : vr_track_kernel<INTEG_DELTA, false, true>; break;
@@ -623,6 +650,7 @@ int vr_backend_create(int device, vr_backend** out)
     if ((e = hipMalloc((void**)&b->d_work, 256)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&b->d_counters, sizeof(Counters))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&b->d_maxbits, 256)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&b->d_cold, sizeof(TrackCold))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(b->d_counters, 0, sizeof(Counters))) != hipSuccess) return bail("hipMemset", e);
     *out = b;
     return VR_OK;
@@ -634,7 +662,7 @@ void vr_backend_destroy(vr_backend* b)
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void* ptrs[] = { b->d_bricks, b->d_major, b->d_tbricks, b->d_nodes, b->d_tris, b->d_p2s, b->d_dissolve, b->d_samples,
-                     b->d_rows, b->d_offsets, b->d_work, b->d_counters, b->d_maxbits };
+                     b->d_rows, b->d_offsets, b->d_work, b->d_counters, b->d_maxbits, b->d_cold };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (Pass& p : b->passes) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     if (b->stream) (void)hipStreamDestroy(b->stream);

@@ -54,8 +54,10 @@ struct Math<true> {
 };
 template <>
 struct Math<false> {
-    static __device__ __forceinline__ float log_(float x) { return __logf(x); }
-    static __device__ __forceinline__ float exp_(float x) { return __expf(x); }
+    // bare v_log_f32 / v_exp_f32 (base 2): arguments here are normal floats, so the denormal
+    // pre-scaling that __logf/__expf wrap around them (10+ instructions) is not needed
+    static __device__ __forceinline__ float log_(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+    static __device__ __forceinline__ float exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
     static __device__ __forceinline__ void sincos_(float x, float& s, float& c) { s = __sinf(x); c = __cosf(x); }
     static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 };
@@ -183,24 +185,16 @@ __device__ __forceinline__ float grid_fetch(const GridDev& g, f3 p, VoxelCache& 
 // In a voxel with sigma <= 0 the reference's walks only do `tFar += step` with a constant step and
 // no random draw (IntegratorRatioTracking.cpp:84-96, :251-263; IntegratorDeltaTracking.cpp:70-82).
 // empty_run returns how many of those iterations (k >= 1) can be taken at once while every lookup
-// position stays inside the box [lo, lo+size)^3 — the current voxel, or its whole 8^3 brick when
-// the brick's majorant says it is empty — and every new t stays <= t1, and advances t exactly as k
+// position stays inside a box — the current voxel, or its whole 8^3 brick when the brick's majorant
+// says it is empty; the caller passes t_safe = min(exit parameter of the shrunk box, t1) — and
+// every new t stays <= t1, and advances t exactly as k
 // sequential float additions would:  inside one binade [2^e, 2^(e+1)) a float is m * 2^(e-23)
 // with integer m, and fl(t + step) = t + q * 2^(e-23) with q = step / 2^(e-23) rounded to nearest
 // (ties are not handled here: they fall back to a single step), so k additions add k*q to the
 // integer bit pattern of t.  The box is shrunk by `slack` on every side, which covers the rounding
 // of fmaf(t, dir, eye) and of the exit-distance estimate; estimates only ever make k smaller.
-__device__ __forceinline__ uint32_t empty_run(f3 eye, f3 dir, float& t, float t1, float step, float lox, float loy,
-                                              float loz, float size)
+__device__ __forceinline__ uint32_t empty_run(float& t, float t_safe, float step)
 {
-    const float slack = 0.01f;
-    const float px = dir.x > 0 ? lox + size - slack : lox + slack;
-    const float py = dir.y > 0 ? loy + size - slack : loy + slack;
-    const float pz = dir.z > 0 ? loz + size - slack : loz + slack;
-    const float tx = dir.x != 0 ? (px - eye.x) * __builtin_amdgcn_rcpf(dir.x) : VR_FLT_MAX;
-    const float ty = dir.y != 0 ? (py - eye.y) * __builtin_amdgcn_rcpf(dir.y) : VR_FLT_MAX;
-    const float tz = dir.z != 0 ? (pz - eye.z) * __builtin_amdgcn_rcpf(dir.z) : VR_FLT_MAX;
-    const float t_safe = fminf(fminf(tx, ty), fminf(tz, t1));
     const uint32_t tb = __float_as_uint(t);
     const uint32_t et = tb >> 23;                                  // t > 0: sign bit clear
     uint32_t k = 1;

@@ -51,20 +51,29 @@ struct WorkDev {
     uint32_t           step_limit;
 };
 
-struct TrackParams {
+// Parameters only the event phases read (path set-up, scatter, shadow start/end).  They live in
+// device memory and are read with ordinary loads there, so that they do not occupy scalar
+// registers across the step loop.
+struct TrackCold {
     CameraDev cam;
+    float     inv_mat[9], vec[3];
+    float     bmin[3], bmax1[3];     // float(bbox.min), float(bbox.max + 1)
+    float     g;
+    float     light[3], light_color[3];
+    uint32_t  max_depth;
+};
+// Kernel argument: what the step loop reads.
+struct TrackParams {
+    const TrackCold* cold;
     WorkDev   work;
     GridDev   density, temperature;
     const float* majorant;           // per-brick max of the density grid
     int32_t   has_temperature;
-    float     inv_mat[9], vec[3];
-    float     bmin[3], bmax1[3];     // float(bbox.min), float(bbox.max + 1)
+    int32_t   use_span;              // steps are much shorter than a voxel: remember the voxel's t-interval
     float     sigma_a, sigma_s, sigma_maj;
     float     t_min, t_max, step_mult;
     float     light_mult, shadow_mult;
-    float     g;
-    float     light[3], light_color[3], emission[3], medium[3], background[3];
-    uint32_t  max_depth;
+    float     emission[3], medium[3], background[3];
 };
 
 // primary ray of (abs column i, abs row j, sub-sample s)                  BaseIntegrator.cpp:35-64
@@ -103,7 +112,24 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 // =============================================================================================
 // ratio / delta tracking
 // =============================================================================================
-#define VR_STEPS_PER_ROUND 32
+// Lane states.  The kernel alternates between a STEP LOOP, in which every walking lane runs the
+// same code (one iteration of the reference's while loop per trip, camera walk and shadow walk
+// alike), and an EVENT PHASE, in which lanes that left the loop are served together: scatter
+// events start their shadow walk, finished shadow walks add the light and pick the new direction,
+// finished paths store their sample and take the next work item.  A lane that meets an event waits
+// (a few iterations) for the phase instead of dragging the whole wave through the long, rare code.
+enum { ST_NEED = 0, ST_WALK = 1, ST_SCATTER = 2, ST_SHADOW_DONE = 3, ST_FINISHED = 4, ST_EXHAUSTED = 5 };
+#define VR_ROUND_MAX 24      // step-loop trips before the event phase runs regardless
+#define VR_ROUND_EVENTS 6    // ... or as soon as this many lanes wait for it
+
+// hide a pointer's provenance: loads through it stay ordinary vector loads inside the phase
+template <typename T>
+__device__ __forceinline__ const T* opaque(const T* p)
+{
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+v"(v));
+    return (const T*)v;
+}
 
 // SKIP: take runs of empty-space iterations at once (empty_run, vr_device.h) — same results bit
 // for bit, fewer trips through the loop.
@@ -113,13 +139,13 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
     typedef Math<EXACT> M;
     const int      lane = threadIdx.x & 63;
     const uint32_t k0 = p.work.key0, k1 = p.work.key1;
-    const f3       light = mk3(p.light[0], p.light[1], p.light[2]);
 
     // ---- per-lane path state (HandleIntersectionData, BaseIntegrator.h:21-50) ----
-    bool     alive = false, exhausted = false;
+    uint32_t st = ST_NEED;
     bool     shadow = false;            // walking directLightningRayMarch
     uint32_t item = 0;
     f3       eye = mk3(0, 0, 0), dir = mk3(0, 0, 1);   // current index-space ray (camera walk or shadow walk)
+    f3       inv = mk3(0, 0, 1);        // 1/dir, for the voxel-span and empty-run estimates only
     float    t = 0, t1 = 0, t0 = 0;     // tFar, iRay.t1(), iRay.t0()
     f3       wdir = mk3(0, 0, 1);       // data->rayDirection
     f3       radiance = mk3(0, 0, 0);   // data->radiance / result
@@ -127,18 +153,111 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
     int      depth_remaining = 0;
     f3       scatter_p = mk3(0, 0, 0);  // iRay(tFar) of the pending scatter event
     float    scatter_len = 0;           // its pathLength
-    uint32_t steps = 0;
     uint32_t rng_pixel = 0, rng_sample = 0, rng_tag = 0, rng_step = 0;   // Philox counter (vr_device.h)
-    VoxelCache vc = { 0xffffffffu, 0.0f }, vct = { 0xffffffffu, 0.0f };
-    uint32_t   brick_id = 0xffffffffu;  // one-entry cache of "this brick's majorant is <= 0"
-    bool       brick_empty = false;
+    // density at iRay(tFar), fetched at the END of the previous trip so that its latency hides
+    // behind the loop overhead and the next trip's Philox block
+    float    cur_val = 0.0f;
+    uint32_t cur_off = 0xffffffffu;     // its voxel offset (0xffffffff: outside the bbox)
+    float    t_span = 0.0f;             // while t < t_span the walk is provably still inside that voxel
+    uint32_t brick_id = 0xffffffffu;    // one-entry cache of "this brick's majorant is <= 0"
+    bool     brick_empty = false;
     unsigned long long n_lookups = 0;
     uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0;
 
+    // value at iRay(t) for the coming trip (nearest voxel by floor, background outside)
+    auto prefetch = [&]() {
+        if (p.use_span && t < t_span) return;                  // same voxel, nothing to do
+        const f3 q = ray_at(eye, dir, t);
+        const float fx = floorf(q.x), fy = floorf(q.y), fz = floorf(q.z);
+        const int32_t i = (int32_t)fx - p.density.min[0], j = (int32_t)fy - p.density.min[1], k = (int32_t)fz - p.density.min[2];
+        const bool in = (uint32_t)i < (uint32_t)p.density.dim[0] && (uint32_t)j < (uint32_t)p.density.dim[1] &&
+                        (uint32_t)k < (uint32_t)p.density.dim[2];
+        if (!in) { cur_val = p.density.background; cur_off = 0xffffffffu; t_span = t; return; }
+        const uint32_t off = brick_offset(p.density, (uint32_t)i, (uint32_t)j, (uint32_t)k);
+        if (off != cur_off) { cur_val = p.density.bricks[off]; cur_off = off; }
+        if (p.use_span || SKIP) {
+            // exit parameter of the voxel shrunk by `slack` on every side (see empty_run)
+            const float slack = 0.01f;
+            const float px = dir.x > 0 ? fx + (1.0f - slack) : fx + slack;
+            const float py = dir.y > 0 ? fy + (1.0f - slack) : fy + slack;
+            const float pz = dir.z > 0 ? fz + (1.0f - slack) : fz + slack;
+            const float tx = dir.x != 0 ? (px - eye.x) * inv.x : VR_FLT_MAX;
+            const float ty = dir.y != 0 ? (py - eye.y) * inv.y : VR_FLT_MAX;
+            const float tz = dir.z != 0 ? (pz - eye.z) * inv.z : VR_FLT_MAX;
+            t_span = fminf(fminf(tx, ty), tz);
+        }
+    };
+    auto set_ray = [&](f3 e, f3 d, float a, float b) {
+        eye = e; dir = d; t = a; t1 = b;
+        inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+        t_span = a;   // force a lookup
+        prefetch();
+    };
+
     for (;;) {
-        // ---------------- refill: terminated lanes take the next items ----------------
+        // =========================== event phase ===========================
+        // (1) scatter events of the ratio tracker start their shadow walk        IntegratorRatioTracking.cpp:213-234
+        if (INTEG == INTEG_RATIO && __any(st == ST_SCATTER)) {
+            if (st == ST_SCATTER) {
+                const TrackCold* c = opaque(p.cold);
+                const f3 light = mk3(c->light[0], c->light[1], c->light[2]);
+                n_shadow++;
+                const f3 so = ray_at(eye, dir, t0);                               // :226 (segment START)
+                rng_tag |= 0x80000000u; rng_step = 0;
+                float c0 = 1e-5f, c1 = VR_FLT_MAX;
+                if (!ray_clip(so, light, c0, c1, c->bmin, c->bmax1)) {            // :229-232
+                    Tsh = 1.0f; st = ST_SHADOW_DONE;
+                } else {
+                    shadow = true; Tsh = 1.0f; st = ST_WALK;
+                    set_ray(so, light, c0, c1);
+                }
+            }
+        }
+        // (2) finished shadow walks (and every scatter of the delta tracker): light, new direction
+        if (__any(st == ST_SHADOW_DONE)) {
+            if (st == ST_SHADOW_DONE) {
+                const TrackCold* c = opaque(p.cold);
+                if (INTEG == INTEG_RATIO) {
+                    rng_tag &= 0x7fffffffu;   // back on the camera stream
+                    const f3 light = mk3(c->light[0], c->light[1], c->light[2]);
+                    const float cos_theta = dot3(wdir, light);                            // :144
+                    const float hg = hg_phase(c->g, cos_theta);                           // :145
+                    f3 nee = scale3(mk3(c->light_color[0], c->light_color[1], c->light_color[2]), T * Tsh); // :147-152
+                    nee = scale3(nee, scatter_len);
+                    nee = scale3(nee, hg);
+                    radiance = add3(radiance, nee);
+                }
+                uint32_t h0, h1, h2, h3;
+                philox4x32_10(rng_pixel, rng_sample, rng_tag | 0x40000000u, 0u, k0, k1, h0, h1, h2, h3);
+                const float xi1 = in_range(h0, 0.0f, 0.9999f);
+                const float xi2 = in_range(h1, 0.0f, 0.9999f);
+                const f3 scattered = hg_sample<EXACT>(c->g, wdir, xi1, xi2);              // :156-159
+                wdir = scattered;                                                         // :178
+                rng_tag += 1; rng_step = 0;
+                shadow = false;
+                float c0 = 1e-5f, c1 = VR_FLT_MAX;
+                if (!ray_clip(scatter_p, scattered, c0, c1, c->bmin, c->bmax1)) {         // :182-187 "scattering failed"
+                    st = ST_FINISHED;
+                } else if (depth_remaining <= 0) {
+                    // `while (... && depthRemaining > 0)`: out of scatter budget, the walk ends as
+                    // escaped                                                            :55, :208 (delta :54, :175)
+                    const f3 bg = mk3(p.background[0], p.background[1], p.background[2]);
+                    radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, T) : bg);
+                    st = ST_FINISHED;
+                } else {
+                    t0 = c0; st = ST_WALK;                                                // :179, :189
+                    set_ray(scatter_p, scattered, c0, c1);
+                }
+            }
+        }
+        // (3) finished paths store their sample
+        if (st == ST_FINISHED) {
+            store_sample(p.work.samples, item, radiance);
+            st = ST_NEED;
+        }
+        // (4) refill: idle lanes take the next items
         for (;;) {
-            const bool               want = !alive && !exhausted;
+            const bool               want = st == ST_NEED;
             const unsigned long long need = __ballot(want);
             if (need == 0ull) break;
             const int leader = __ffsll((long long)need) - 1;
@@ -148,79 +267,75 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
             if (want) {
                 const uint32_t mine = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                 if (mine >= p.work.nitems) {
-                    exhausted = true;
+                    st = ST_EXHAUSTED;
                 } else {
+                    const TrackCold* c = opaque(p.cold);
                     item = mine;
-                    const uint32_t x = mine % p.cam.width;
-                    const uint32_t q = mine / p.cam.width;
-                    const uint32_t r = q % p.cam.nrows;
-                    const uint32_t sl = q / p.cam.nrows;
-                    const uint32_t s = p.cam.s_first + sl;
-                    const uint32_t ci = p.cam.x0 + x;
-                    const uint32_t cj = p.cam.y0 + p.cam.row_first + r * p.cam.row_stride;
+                    const uint32_t x = mine % c->cam.width;
+                    const uint32_t q = mine / c->cam.width;
+                    const uint32_t r = q % c->cam.nrows;
+                    const uint32_t sl = q / c->cam.nrows;
+                    const uint32_t s = c->cam.s_first + sl;
+                    const uint32_t ci = c->cam.x0 + x;
+                    const uint32_t cj = c->cam.y0 + c->cam.row_first + r * c->cam.row_stride;
                     n_paths++;
                     // castRay prologue                      IntegratorRatioTracking.cpp:13-53
-                    wdir = primary_direction(p.cam, ci, cj, s);
-                    f3 weye = mk3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+                    wdir = primary_direction(c->cam, ci, cj, s);
+                    const f3 weye = mk3(c->cam.pos[0], c->cam.pos[1], c->cam.pos[2]);
                     // wRay.worldToIndexF(grid)               Ray.h:257-267, NanoVDB.h:2262-2270
-                    eye = mat_mult(p.inv_mat, mk3(weye.x - p.vec[0], weye.y - p.vec[1], weye.z - p.vec[2]));
-                    f3    idir = mat_mult(p.inv_mat, wdir);
-                    float length = sqrtf(idir.x * idir.x + idir.y * idir.y + idir.z * idir.z);
-                    float inv_length = 1.0f / length;
-                    dir = mk3(inv_length * idir.x, inv_length * idir.y, inv_length * idir.z);
+                    const f3 ieye = mat_mult(c->inv_mat, mk3(weye.x - c->vec[0], weye.y - c->vec[1], weye.z - c->vec[2]));
+                    const f3 idir = mat_mult(c->inv_mat, wdir);
+                    const float length = sqrtf(idir.x * idir.x + idir.y * idir.y + idir.z * idir.z);
+                    const float inv_length = 1.0f / length;
+                    const f3 ndir = mk3(inv_length * idir.x, inv_length * idir.y, inv_length * idir.z);
                     float c0 = length * 1e-5f, c1 = VR_FLT_MAX;
-                    if (!ray_clip(eye, dir, c0, c1, p.bmin, p.bmax1) || p.max_depth == 0) {
+                    if (!ray_clip(ieye, ndir, c0, c1, c->bmin, c->bmax1) || c->max_depth == 0) {
                         // missed the grid (:37-39), or a zero scatter budget: the loop never runs (:55, :208)
                         store_sample(p.work.samples, item, mk3(p.background[0], p.background[1], p.background[2]));
                     } else {
-                        alive = true; shadow = false;
-                        t0 = c0; t1 = c1; t = c0;
+                        st = ST_WALK; shadow = false;
+                        t0 = c0;
                         radiance = mk3(0, 0, 0);
                         T = 1.0f;
-                        depth_remaining = (int)p.max_depth;
-                        steps = 0;
+                        depth_remaining = (int)c->max_depth;
                         rng_pixel = (cj << 16) | ci; rng_sample = s; rng_tag = 0; rng_step = 0;
-                        vc.idx = 0xffffffffu; vct.idx = 0xffffffffu;
+                        cur_off = 0xffffffffu;
+                        set_ray(ieye, ndir, c0, c1);
                     }
                 }
             }
         }
-        if (!__any(alive)) break;
+        if (!__any(st == ST_WALK)) break;   // every lane exhausted (events were all served above)
 
-        // ---------------- a round of steps, no refill checks inside ----------------
+        // =========================== step loop ===========================
 #pragma unroll 1
-        for (int it = 0; it < VR_STEPS_PER_ROUND; ++it) {
-            if (alive) {
-                bool  finished = false;      // path over: write `radiance`
-                bool  shadow_done = false;   // shadow walk over: resume the scatter event
-                float light_T = 1.0f;
+        for (int it = 0; it < VR_ROUND_MAX; ++it) {
+            if (st == ST_WALK) {
                 const bool in_shadow = (INTEG == INTEG_RATIO) && shadow;
+                // this iteration's random block; does not depend on the voxel still in flight
+                uint32_t w0, w1, w2, w3;
+                philox4x32_10(rng_pixel, rng_sample, rng_tag, rng_step, k0, k1, w0, w1, w2, w3);
 
                 // sigma = multiplier * acc.getValue(Coord::Floor(iRay(tFar)))                :71 / :238
-                // (looked up ahead of the roulette so that the wave generates its random block once;
-                //  a path the roulette ends does not count the lookup, as in the reference)
-                int32_t     vi, vj, vk;
-                bool        inside;
                 const float mult = in_shadow ? p.shadow_mult : p.light_mult;
-                const float sigma = mult * grid_fetch(p.density, ray_at(eye, dir, t), vc, vi, vj, vk, inside);
-                const bool  roulette = INTEG == INTEG_RATIO && !in_shadow && T < 0.05f;
-                uint32_t    w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-                if (sigma > 0.0f || roulette) philox4x32_10(rng_pixel, rng_sample, rng_tag, rng_step, k0, k1, w0, w1, w2, w3);
+                const float sigma = mult * cur_val;
+                bool walking = true;
 
-                if (steps > p.work.step_limit) { n_limit++; finished = true; }
-                if (roulette) {
+                if (rng_step > p.work.step_limit) { n_limit++; st = ST_FINISHED; walking = false; }
+                if (INTEG == INTEG_RATIO && !in_shadow && T < 0.05f) {
                     // Russian roulette on the camera walk     IntegratorRatioTracking.cpp:57-69
+                    // (a path it ends does not count the lookup above, as in the reference)
                     const float q = 0.75f;
                     if (in_range(w0, 0.0f, 1.0f) < q) T = 0.0f;
                     else T /= 1.0f - q;
-                    if (T <= 0.0f) finished = true;
+                    if (T <= 0.0f) { st = ST_FINISHED; walking = false; }
                 }
 
-                if (!finished) {
+                if (walking) {
                     const float mu_a = sigma * p.sigma_a;
                     const float mu_s = sigma * p.sigma_s;
                     const float mu_t = mu_a + mu_s;
-                    const float tmin = in_shadow ? p.t_min * 5 : p.t_min;                       // :216
+                    const float tmin = in_shadow ? p.t_min * 5 : p.t_min;                     // :216
                     float    len;
                     uint32_t krun = 1;
                     if (sigma > 0.0f) {
@@ -232,27 +347,40 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                         t += len;                                                             // :88 / :255
                     } else {
                         len = in_shadow ? tmin * 100 : tmin * 10;                             // :252 / :85
-                        if (SKIP && inside) {
-                            const uint32_t bid = vc.idx >> 9;
+                        if (SKIP && cur_off != 0xffffffffu) {
+                            const uint32_t bid = cur_off >> 9;
                             if (bid != brick_id) { brick_id = bid; brick_empty = p.majorant[bid] <= 0.0f && mult >= 0.0f; }
-                            const int32_t m = brick_empty ? ~7 : ~0;
-                            krun = empty_run(eye, dir, t, t1, len, (float)(p.density.min[0] + (vi & m)),
-                                             (float)(p.density.min[1] + (vj & m)), (float)(p.density.min[2] + (vk & m)),
-                                             brick_empty ? 8.0f : 1.0f);
+                            float t_safe = t_span;      // this (empty) voxel's shrunk exit
+                            if (brick_empty) {
+                                // the whole 8^3 brick is empty: run to ITS shrunk exit
+                                const float slack = 0.01f;
+                                const uint32_t bk = bid % (uint32_t)p.density.nb[2], bq = bid / (uint32_t)p.density.nb[2];
+                                const uint32_t bj = bq % (uint32_t)p.density.nb[1], bi = bq / (uint32_t)p.density.nb[1];
+                                const float lx = (float)(p.density.min[0] + (int32_t)(bi << 3));
+                                const float ly = (float)(p.density.min[1] + (int32_t)(bj << 3));
+                                const float lz = (float)(p.density.min[2] + (int32_t)(bk << 3));
+                                const float px = dir.x > 0 ? lx + (8.0f - slack) : lx + slack;
+                                const float py = dir.y > 0 ? ly + (8.0f - slack) : ly + slack;
+                                const float pz = dir.z > 0 ? lz + (8.0f - slack) : lz + slack;
+                                const float tx = dir.x != 0 ? (px - eye.x) * inv.x : VR_FLT_MAX;
+                                const float ty = dir.y != 0 ? (py - eye.y) * inv.y : VR_FLT_MAX;
+                                const float tz = dir.z != 0 ? (pz - eye.z) * inv.z : VR_FLT_MAX;
+                                t_safe = fminf(fminf(tx, ty), tz);
+                            }
+                            krun = empty_run(t, fminf(t_safe, t1), len);
                         } else {
                             t += len;
                         }
                     }
                     n_lookups += krun;
                     rng_step += krun;
-                    steps += krun;
                     if (t > t1) {                                                             // :91 / :258
-                        if (in_shadow) { shadow_done = true; light_T = Tsh; }
+                        if (in_shadow) { st = ST_SHADOW_DONE; }                               // returns transmission
                         else {
                             // survivor: radiance + background * transmission                 :208 (delta :175)
                             const f3 bg = mk3(p.background[0], p.background[1], p.background[2]);
                             radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, T) : bg);
-                            finished = true;
+                            st = ST_FINISHED;
                         }
                     } else if (sigma > 0.0f) {
                         if (in_shadow) {
@@ -262,7 +390,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                                 if (in_range(w2, 0.0f, 1.0f) < q) Tsh = 0.0f;
                                 else Tsh /= 1.0f - q;
                             }
-                            if (Tsh <= 0.0f) { shadow_done = true; light_T = Tsh; }           // :281
+                            if (Tsh <= 0.0f) st = ST_SHADOW_DONE;                             // :281
                         } else {
                             const float pA = M::div_(mu_a, p.sigma_maj);                      // :98-100
                             const float pS = M::div_(mu_s, p.sigma_maj);
@@ -271,7 +399,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                             if (INTEG == INTEG_RATIO) T = T * M::exp_(-(len)*mu_t);           // :103-105
                             const float sample = in_range(w2, 0.0f, 1.0f);                    // :108
                             if (INTEG == INTEG_RATIO && p.has_temperature) {                  // :110-122
-                                const float emission = grid_value(p.temperature, ray_at(eye, dir, t), vct);
+                                const float emission = grid_value_nocache(p.temperature, ray_at(eye, dir, t));
                                 n_lookups++;
                                 if (emission > 0.0f) {
                                     f3 e = scale3(mk3(p.emission[0], p.emission[1], p.emission[2]), T * mu_a);
@@ -287,79 +415,31 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                                     radiance = add3(radiance, scale3(mk3(p.medium[0], p.medium[1], p.medium[2]), T));
                                 } else {                                                      // delta :101-113
                                     if (p.has_temperature) {
-                                        (void)grid_value(p.temperature, ray_at(eye, dir, t), vct);
-                                        n_lookups++;
+                                        n_lookups++;   // accEmission.getValue, result unused (:103)
                                         radiance = add3(radiance, scale3(mk3(p.emission[0], p.emission[1], p.emission[2]), mu_a));
                                     }
                                     radiance = add3(radiance, mk3(p.medium[0], p.medium[1], p.medium[2]));
                                 }
-                                finished = true;
+                                st = ST_FINISHED;
                             } else {
                                 // scattering                                                :133-191 (delta :115-158)
                                 depth_remaining--;                                            // :136 (the `< 0` test never fires)
                                 n_scatter++;
-                                if (INTEG == INTEG_DELTA) {
-                                    scatter_p = ray_at(eye, dir, t);
-                                    shadow_done = true;     // no shadow walk: go straight to the new direction
-                                } else if (T > 0.0f) {                                        // :141
-                                    // directLightningRayMarch prologue                       :213-234
-                                    n_shadow++;
-                                    scatter_p = ray_at(eye, dir, t);
+                                if (INTEG == INTEG_DELTA || T > 0.0f) {                       // :141
+                                    scatter_p = ray_at(eye, dir, t);                          // :162 (delta :130)
                                     scatter_len = len;
-                                    const f3 so = ray_at(eye, dir, t0);                       // :226 (segment START)
-                                    rng_tag |= 0x80000000u; rng_step = 0;
-                                    float c0 = 1e-5f, c1 = VR_FLT_MAX;
-                                    if (!ray_clip(so, light, c0, c1, p.bmin, p.bmax1)) {      // :229-232
-                                        shadow_done = true; light_T = 1.0f;
-                                    } else {
-                                        shadow = true;
-                                        eye = so; dir = light; t = c0; t1 = c1; Tsh = 1.0f;
-                                    }
+                                    st = INTEG == INTEG_DELTA ? ST_SHADOW_DONE : ST_SCATTER;
                                 }
                             }
                         }
                     }
-                }
-
-                if (shadow_done && !finished) {
-                    if (INTEG == INTEG_RATIO) {
-                        rng_tag &= 0x7fffffffu;   // back on the camera stream
-                        const float cos_theta = dot3(wdir, light);                            // :144
-                        const float hg = hg_phase(p.g, cos_theta);                            // :145
-                        f3 nee = scale3(mk3(p.light_color[0], p.light_color[1], p.light_color[2]), T * light_T); // :147-152
-                        nee = scale3(nee, scatter_len);
-                        nee = scale3(nee, hg);
-                        radiance = add3(radiance, nee);
-                    }
-                    uint32_t h0, h1, h2, h3;
-                    philox4x32_10(rng_pixel, rng_sample, rng_tag | 0x40000000u, 0u, k0, k1, h0, h1, h2, h3);
-                    const float xi1 = in_range(h0, 0.0f, 0.9999f);
-                    const float xi2 = in_range(h1, 0.0f, 0.9999f);
-                    const f3 scattered = hg_sample<EXACT>(p.g, wdir, xi1, xi2);               // :156-159
-                    wdir = scattered;                                                         // :178
-                    eye = scatter_p; dir = scattered;                                         // :179
-                    rng_tag += 1; rng_step = 0;
-                    shadow = false;
-                    float c0 = 1e-5f, c1 = VR_FLT_MAX;
-                    if (!ray_clip(eye, dir, c0, c1, p.bmin, p.bmax1)) {                       // :182-187 "scattering failed"
-                        finished = true;
-                    } else {
-                        t0 = c0; t1 = c1; t = c0;                                             // :189
-                        // `while (... && depthRemaining > 0)`: out of scatter budget, the walk ends as
-                        // escaped                                                            :55, :208 (delta :54, :175)
-                        if (depth_remaining <= 0) {
-                            const f3 bg = mk3(p.background[0], p.background[1], p.background[2]);
-                            radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, T) : bg);
-                            finished = true;
-                        }
-                    }
-                }
-
-                if (finished) {
-                    store_sample(p.work.samples, item, radiance);
-                    alive = false;
+                    if (st == ST_WALK) prefetch();
                 }
             }
+            // leave for the event phase once enough lanes wait for it, or none walks any more
+            const int n_walk = __popcll(__ballot(st == ST_WALK));
+            const int n_event = __popcll(__ballot(st == ST_SCATTER || st == ST_SHADOW_DONE || st == ST_FINISHED));
+            if (n_event >= VR_ROUND_EVENTS || n_walk == 0) break;
         }
     }
 
