@@ -132,23 +132,17 @@ def main():
     be.set_seed(scenes.SEED)
     be.generate_cloud(n, scenes.cloud_radius(n))     # density resident in HBM before timing
 
-    rows_max = (H + world - 1) // world
-    my_rows = len(range(rank, H, world))
-    part = torch.zeros((rows_max, W, 3), dtype=torch.float32, device=dev)
-    gathered = torch.zeros((world, rows_max, W, 3), dtype=torch.float32, device=dev) if world > 1 else None
-    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+    from volume_renderer_amd.scheduler import RowScheduler
+    sched = RowScheduler(H, W, dev, rank=rank, world=world)
+
+    def render_rows(first, stride, count, out):
+        be.render_row_set_device(opts, integ_id, first, stride, count, out.data_ptr())
+        be.synchronize()
 
     def step():
-        be.render_row_set_device(opts, integ_id, rank, world, my_rows, part.data_ptr())
-        be.synchronize()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, part)
-            if rank == 0:
-                for r in range(world):
-                    k = len(range(r, H, world))
-                    frame[r::world] = gathered[r, :k]
-        else:
-            frame.copy_(part[:H])
+        return sched.render(render_rows)
+
+    frame = sched.frame
 
     def fence():
         torch.cuda.synchronize()
@@ -213,6 +207,8 @@ def main():
             },
             "glookups_per_s": lookups_all / max(kernel_ms_all / 1e3 / world, 1e-12) / 1e9,
             "lookups_per_sample": lookups_all / (samples_per_step * a.steps),
+            "divergence": {k: stats[k] for k in ("wave_trips", "wave_trip_lanes", "event_phases", "scatter_events")}
+            | {"walking_lanes_per_trip": stats["wave_trip_lanes"] / max(stats["wave_trips"], 1)},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S, "traffic": traffic,

@@ -106,6 +106,10 @@ typedef struct vr_render_stats {
     uint64_t shadow_rays;      /* directLightningRayMarch calls / marcher light rays */
     uint64_t ray_queries;      /* closest-hit queries (rtcIntersect1 in the reference) */
     uint64_t step_limit_hits;  /* paths cut by the safety cap (0 in any valid run) */
+    /* wave-level divergence counters of the GPU tracking kernel (0 from the CPU oracle) */
+    uint64_t wave_trips;       /* trips of a wave through the step loop */
+    uint64_t wave_trip_lanes;  /* lanes that were walking, summed over those trips (<= 64 per trip) */
+    uint64_t event_phases;     /* event phases run by a wave (scatter / shadow end / refill) */
 } vr_render_stats;
 
 /* Error codes returned by every vr_* entry point (0 = success).  The reference has no

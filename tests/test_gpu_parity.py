@@ -194,3 +194,47 @@ def test_errors_are_reported_not_thrown(backend, cloud64):
             b2.render(o, 7)
     finally:
         b2.close()
+
+
+def test_device_postprocess_matches_oracle(backend, oracle):
+    """max-white scan + extended Reinhard (BaseIntegrator.cpp:199-220) on a device buffer."""
+    import torch
+    rng = np.random.default_rng(9)
+    img = rng.uniform(0, 6, size=(37, 53, 3)).astype(np.float32)
+    dev = torch.from_numpy(img).to("cuda:0")
+    assert backend.max_channel_device(dev.data_ptr(), 37 * 53) == img.max()
+    want = img.copy()
+    m = oracle.vro_tonemap_reinhard_extended(ol.fptr(want), 37 * 53)
+    got_m = backend.tonemap_device(dev.data_ptr(), 37 * 53)
+    assert got_m == m and bitexact(dev.cpu().numpy(), want)
+    # multi-GPU form: the caller supplies the global white point
+    dev2 = torch.from_numpy(img).to("cuda:0")
+    backend.tonemap_device(dev2.data_ptr(), 37 * 53, max_white=float(m))
+    assert bitexact(dev2.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("integ", [RATIO, DELTA])
+def test_fast_mode_is_statistically_the_reference_estimator(backend, oracle, cloud64, integ):
+    """north_star: stochastic integrators match the reference's converged image within confidence
+    bounds.  Reference side: the oracle with the reference's own RNG scheme (mt19937 per row chunk,
+    libm); GPU side: fast mode, Philox.  Independent streams, so compare per-pixel means with a
+    z-test from the per-pixel sample variance, and the image mean tightly."""
+    W, H, spp = 40, 40, 256
+    o = scenes.options_cloud(integ, 64, W, H, spp, regime="shipped")
+    sc, _ = ol.make_scene(density=cloud64)
+    oracle.vro_set_math_mode(ol.MATH_LIBM)
+    _, per_sample, _ = ol.render_rows(sc, o, integ, 0, H, rng_mode=ol.RNG_REFERENCE, per_sample=True)
+    ref_mean = per_sample.mean(axis=2)
+    ref_var = per_sample.var(axis=2, ddof=1)
+    backend.set_density(cloud64)
+    backend.set_mode(MODE_FAST)
+    backend.set_seed(scenes.SEED)
+    got = backend.render(o, integ)
+    # both sides are means of spp samples with (about) the same per-sample variance
+    se = np.sqrt(2.0 * ref_var / spp) + 1e-6
+    z = np.abs(got - ref_mean) / se
+    assert np.mean(z < 4.0) > 0.995, np.mean(z < 4.0)
+    rel = abs(got.mean() - ref_mean.mean()) / ref_mean.mean()
+    rmse = float(np.sqrt(np.mean((got - ref_mean) ** 2)))
+    print(f"integrator {integ}: image-mean rel diff {rel:.4f}, RMSE {rmse:.4f}, max z {z.max():.2f}")
+    assert rel < 0.02

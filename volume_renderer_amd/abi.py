@@ -100,6 +100,9 @@ class RenderStats(C.Structure):
         ("shadow_rays", C.c_uint64),
         ("ray_queries", C.c_uint64),
         ("step_limit_hits", C.c_uint64),
+        ("wave_trips", C.c_uint64),
+        ("wave_trip_lanes", C.c_uint64),
+        ("event_phases", C.c_uint64),
     ]
 
     def as_dict(self):

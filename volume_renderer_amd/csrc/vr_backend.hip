@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -416,6 +417,15 @@ int make_camera(vr_backend* b, const vr_options_pod* o, CameraDev& c)
     return VR_OK;
 }
 
+// developer knob: integer from the environment, else the built-in default
+int tune_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    const int x = atoi(v);
+    return x > 0 ? x : dflt;
+}
+
 float ulp_of(float v)
 {
     v = std::fabs(v);
@@ -549,6 +559,8 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             for (int i = 0; i < 3; ++i) {
                 p.emission[i] = o->emissionColor[i]; p.medium[i] = o->mediumColor[i]; p.background[i] = o->backgroundColor[i];
             }
+            p.round_max = tune_int("VR_TUNE_ROUND_MAX", VR_ROUND_MAX);
+            p.round_events = tune_int("VR_TUNE_ROUND_EVENTS", VR_ROUND_EVENTS);
             // typical free path (index units) well under a voxel: remember each voxel's t-interval
             {
                 const float mean_free = p.sigma_maj > 0.0f ? o->stepSizeMultiplier / p.sigma_maj : 1e30f;
@@ -608,6 +620,7 @@ int collect(vr_backend* b)
     b->stats.path_samples = c.path_samples; b->stats.density_lookups = c.density_lookups;
     b->stats.scatter_events = c.scatter_events; b->stats.shadow_rays = c.shadow_rays;
     b->stats.ray_queries = c.ray_queries; b->stats.step_limit_hits = c.step_limit_hits;
+    b->stats.wave_trips = c.wave_trips; b->stats.wave_trip_lanes = c.wave_trip_lanes; b->stats.event_phases = c.event_phases;
     if (c.step_limit_hits) return fail(b, VR_ERR_STEP_LIMIT, "%llu paths hit the per-path step cap", (unsigned long long)c.step_limit_hits);
     return VR_OK;
 }

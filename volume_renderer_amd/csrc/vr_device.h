@@ -76,8 +76,11 @@ struct Math<false> {
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
 {
+#ifndef VR_PHILOX_ROUNDS
+#define VR_PHILOX_ROUNDS 10   // anything else is a timing experiment, never a shipped build
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < VR_PHILOX_ROUNDS; ++r) {
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
         const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;

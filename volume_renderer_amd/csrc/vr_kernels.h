@@ -25,6 +25,7 @@ enum { INTEG_RATIO = 2, INTEG_DELTA = 3 };
 
 struct Counters {
     unsigned long long path_samples, density_lookups, scatter_events, shadow_rays, ray_queries, step_limit_hits;
+    unsigned long long wave_trips, wave_trip_lanes, event_phases;
 };
 
 // Camera block: renderPartial's per-chunk constants + renderRay's per-pixel arithmetic
@@ -70,6 +71,7 @@ struct TrackParams {
     const float* majorant;           // per-brick max of the density grid
     int32_t   has_temperature;
     int32_t   use_span;              // steps are much shorter than a voxel: remember the voxel's t-interval
+    int32_t   round_max, round_events; // step-loop trips per round / waiting lanes that end a round early
     float     sigma_a, sigma_s, sigma_maj;
     float     t_min, t_max, step_mult;
     float     light_mult, shadow_mult;
@@ -159,10 +161,12 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
     float    cur_val = 0.0f;
     uint32_t cur_off = 0xffffffffu;     // its voxel offset (0xffffffff: outside the bbox)
     float    t_span = 0.0f;             // while t < t_span the walk is provably still inside that voxel
-    uint32_t brick_id = 0xffffffffu;    // one-entry cache of "this brick's majorant is <= 0"
-    bool     brick_empty = false;
+    float    t_brick = 0.0f;            // same for the voxel's 8^3 brick
+    uint32_t brick_id = 0xffffffffu;    // brick of that voxel and its majorant (fetched with the voxel)
+    float    brick_major = 1.0f;
     unsigned long long n_lookups = 0;
     uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0;
+    unsigned long long w_trips = 0, w_trip_lanes = 0, w_phases = 0;   // wave-uniform divergence counters
 
     // value at iRay(t) for the coming trip (nearest voxel by floor, background outside)
     auto prefetch = [&]() {
@@ -175,16 +179,20 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
         if (!in) { cur_val = p.density.background; cur_off = 0xffffffffu; t_span = t; return; }
         const uint32_t off = brick_offset(p.density, (uint32_t)i, (uint32_t)j, (uint32_t)k);
         if (off != cur_off) { cur_val = p.density.bricks[off]; cur_off = off; }
+        if (SKIP && (off >> 9) != brick_id) { brick_id = off >> 9; brick_major = p.majorant[brick_id]; }
         if (p.use_span || SKIP) {
-            // exit parameter of the voxel shrunk by `slack` on every side (see empty_run)
+            // exit parameters of the voxel, and of its brick, both shrunk by `slack` on every side
+            // (see empty_run)
             const float slack = 0.01f;
-            const float px = dir.x > 0 ? fx + (1.0f - slack) : fx + slack;
-            const float py = dir.y > 0 ? fy + (1.0f - slack) : fy + slack;
-            const float pz = dir.z > 0 ? fz + (1.0f - slack) : fz + slack;
-            const float tx = dir.x != 0 ? (px - eye.x) * inv.x : VR_FLT_MAX;
-            const float ty = dir.y != 0 ? (py - eye.y) * inv.y : VR_FLT_MAX;
-            const float tz = dir.z != 0 ? (pz - eye.z) * inv.z : VR_FLT_MAX;
-            t_span = fminf(fminf(tx, ty), tz);
+            const float bx = (float)(p.density.min[0] + (i & ~7)), by = (float)(p.density.min[1] + (j & ~7)),
+                        bz = (float)(p.density.min[2] + (k & ~7));
+            const bool  gx = dir.x > 0, gy = dir.y > 0, gz = dir.z > 0;
+            const float vx = (gx ? fx + (1.0f - slack) : fx + slack) - eye.x, wx = (gx ? bx + (8.0f - slack) : bx + slack) - eye.x;
+            const float vy = (gy ? fy + (1.0f - slack) : fy + slack) - eye.y, wy = (gy ? by + (8.0f - slack) : by + slack) - eye.y;
+            const float vz = (gz ? fz + (1.0f - slack) : fz + slack) - eye.z, wz = (gz ? bz + (8.0f - slack) : bz + slack) - eye.z;
+            const bool  nx = dir.x != 0, ny = dir.y != 0, nz = dir.z != 0;
+            t_span = fminf(fminf(nx ? vx * inv.x : VR_FLT_MAX, ny ? vy * inv.y : VR_FLT_MAX), nz ? vz * inv.z : VR_FLT_MAX);
+            if (SKIP) t_brick = fminf(fminf(nx ? wx * inv.x : VR_FLT_MAX, ny ? wy * inv.y : VR_FLT_MAX), nz ? wz * inv.z : VR_FLT_MAX);
         }
     };
     auto set_ray = [&](f3 e, f3 d, float a, float b) {
@@ -196,6 +204,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
 
     for (;;) {
         // =========================== event phase ===========================
+        w_phases++;
         // (1) scatter events of the ratio tracker start their shadow walk        IntegratorRatioTracking.cpp:213-234
         if (INTEG == INTEG_RATIO && __any(st == ST_SCATTER)) {
             if (st == ST_SCATTER) {
@@ -309,7 +318,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
 
         // =========================== step loop ===========================
 #pragma unroll 1
-        for (int it = 0; it < VR_ROUND_MAX; ++it) {
+        for (int it = 0; it < p.round_max; ++it) {
             if (st == ST_WALK) {
                 const bool in_shadow = (INTEG == INTEG_RATIO) && shadow;
                 // this iteration's random block; does not depend on the voxel still in flight
@@ -348,25 +357,8 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                     } else {
                         len = in_shadow ? tmin * 100 : tmin * 10;                             // :252 / :85
                         if (SKIP && cur_off != 0xffffffffu) {
-                            const uint32_t bid = cur_off >> 9;
-                            if (bid != brick_id) { brick_id = bid; brick_empty = p.majorant[bid] <= 0.0f && mult >= 0.0f; }
-                            float t_safe = t_span;      // this (empty) voxel's shrunk exit
-                            if (brick_empty) {
-                                // the whole 8^3 brick is empty: run to ITS shrunk exit
-                                const float slack = 0.01f;
-                                const uint32_t bk = bid % (uint32_t)p.density.nb[2], bq = bid / (uint32_t)p.density.nb[2];
-                                const uint32_t bj = bq % (uint32_t)p.density.nb[1], bi = bq / (uint32_t)p.density.nb[1];
-                                const float lx = (float)(p.density.min[0] + (int32_t)(bi << 3));
-                                const float ly = (float)(p.density.min[1] + (int32_t)(bj << 3));
-                                const float lz = (float)(p.density.min[2] + (int32_t)(bk << 3));
-                                const float px = dir.x > 0 ? lx + (8.0f - slack) : lx + slack;
-                                const float py = dir.y > 0 ? ly + (8.0f - slack) : ly + slack;
-                                const float pz = dir.z > 0 ? lz + (8.0f - slack) : lz + slack;
-                                const float tx = dir.x != 0 ? (px - eye.x) * inv.x : VR_FLT_MAX;
-                                const float ty = dir.y != 0 ? (py - eye.y) * inv.y : VR_FLT_MAX;
-                                const float tz = dir.z != 0 ? (pz - eye.z) * inv.z : VR_FLT_MAX;
-                                t_safe = fminf(fminf(tx, ty), tz);
-                            }
+                            // an empty brick (majorant <= 0) is crossed in one run, else this voxel
+                            const float t_safe = (brick_major <= 0.0f && mult >= 0.0f) ? t_brick : t_span;
                             krun = empty_run(t, fminf(t_safe, t1), len);
                         } else {
                             t += len;
@@ -374,6 +366,9 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                     }
                     n_lookups += krun;
                     rng_step += krun;
+                    // the next iteration's voxel, requested as early as its position is known; the
+                    // rest of this iteration and the next Philox block run while it is in flight
+                    if (t <= t1) prefetch();
                     if (t > t1) {                                                             // :91 / :258
                         if (in_shadow) { st = ST_SHADOW_DONE; }                               // returns transmission
                         else {
@@ -433,13 +428,13 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                             }
                         }
                     }
-                    if (st == ST_WALK) prefetch();
                 }
             }
             // leave for the event phase once enough lanes wait for it, or none walks any more
             const int n_walk = __popcll(__ballot(st == ST_WALK));
+            w_trips++; w_trip_lanes += (unsigned)n_walk;
             const int n_event = __popcll(__ballot(st == ST_SCATTER || st == ST_SHADOW_DONE || st == ST_FINISHED));
-            if (n_event >= VR_ROUND_EVENTS || n_walk == 0) break;
+            if (n_event >= p.round_events || n_walk == 0) break;
         }
     }
 
@@ -452,6 +447,9 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
         atomicAdd(&p.work.counters->scatter_events, c);
         atomicAdd(&p.work.counters->shadow_rays, d);
         if (e) atomicAdd(&p.work.counters->step_limit_hits, e);
+        atomicAdd(&p.work.counters->wave_trips, w_trips);
+        atomicAdd(&p.work.counters->wave_trip_lanes, w_trip_lanes);
+        atomicAdd(&p.work.counters->event_phases, w_phases);
     }
 }
 
