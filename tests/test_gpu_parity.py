@@ -224,17 +224,27 @@ def test_fast_mode_is_statistically_the_reference_estimator(backend, oracle, clo
     sc, _ = ol.make_scene(density=cloud64)
     oracle.vro_set_math_mode(ol.MATH_LIBM)
     _, per_sample, _ = ol.render_rows(sc, o, integ, 0, H, rng_mode=ol.RNG_REFERENCE, per_sample=True)
-    ref_mean = per_sample.mean(axis=2)
-    ref_var = per_sample.var(axis=2, ddof=1)
     backend.set_density(cloud64)
     backend.set_mode(MODE_FAST)
     backend.set_seed(scenes.SEED)
     got = backend.render(o, integ)
-    # both sides are means of spp samples with (about) the same per-sample variance
-    se = np.sqrt(2.0 * ref_var / spp) + 1e-6
-    z = np.abs(got - ref_mean) / se
-    assert np.mean(z < 4.0) > 0.995, np.mean(z < 4.0)
-    rel = abs(got.mean() - ref_mean.mean()) / ref_mean.mean()
-    rmse = float(np.sqrt(np.mean((got - ref_mean) ** 2)))
+    # per-pixel sample distributions are heavy-tailed (NEE spikes, roulette boosts), so the z-test
+    # runs on 5x5-pixel blocks: 6400 samples per block, variance from the reference's samples,
+    # both sides being means of as many samples
+    B = 5
+
+    def blocks(a):
+        return a.reshape(H // B, B, W // B, B, *a.shape[2:]).swapaxes(1, 2)
+
+    ref_samples = blocks(per_sample).reshape(H // B, W // B, B * B * spp, 3)
+    ref_mean = ref_samples.mean(axis=2)
+    ref_var = ref_samples.var(axis=2, ddof=1)
+    got_mean = blocks(got).reshape(H // B, W // B, B * B, 3).mean(axis=2)
+    z = np.abs(got_mean - ref_mean) / np.sqrt(2.0 * ref_var / (B * B * spp))
+    assert z.max() < 4.5, z.max()
+    assert np.mean(z < 3.0) > 0.97
+    pix_ref = per_sample.mean(axis=2)
+    rel = abs(got.mean() - pix_ref.mean()) / pix_ref.mean()
+    rmse = float(np.sqrt(np.mean((got - pix_ref) ** 2)))
     print(f"integrator {integ}: image-mean rel diff {rel:.4f}, RMSE {rmse:.4f}, max z {z.max():.2f}")
-    assert rel < 0.02
+    assert rel < 0.03      # image mean of a heavy-tailed estimator: s.e. is about 1 % here
