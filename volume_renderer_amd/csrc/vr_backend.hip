@@ -546,19 +546,20 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             memcpy(cold.bmin, b->bmin, sizeof cold.bmin); memcpy(cold.bmax1, b->bmax1, sizeof cold.bmax1);
             cold.g = o->heyneyGreensteinG;
             for (int i = 0; i < 3; ++i) { cold.light[i] = o->lightPosition[i]; cold.light_color[i] = o->lightColor[i]; }
+            for (int i = 0; i < 3; ++i) {
+                cold.emission[i] = o->emissionColor[i]; cold.medium[i] = o->mediumColor[i]; cold.background[i] = o->backgroundColor[i];
+            }
             cold.max_depth = o->maxDepth;
+            cold.temperature = b->tgrid;
             b->cold_host.push_back(cold);    // stays alive until the stream has consumed the copy
             HIP_TRY(b, hipMemcpyAsync(b->d_cold, &b->cold_host.back(), sizeof(TrackCold), hipMemcpyHostToDevice, b->stream));
             TrackParams p{};
             p.cold = b->d_cold; p.work = work;
-            p.density = b->grid; p.temperature = b->tgrid; p.has_temperature = b->has_temperature ? 1 : 0;
+            p.density = b->grid; p.has_temperature = b->has_temperature ? 1 : 0;
             p.sigma_a = o->sigma_a; p.sigma_s = o->sigma_s;
             p.sigma_maj = b->max_value * (o->sigma_a + o->sigma_s);          // IntegratorRatioTracking.cpp:42-45
             p.t_min = o->stepSizeMin; p.t_max = o->stepSizeMax; p.step_mult = o->stepSizeMultiplier;
             p.light_mult = o->lightRayDensityMultiplier; p.shadow_mult = o->shadowRayDensityMultiplier;
-            for (int i = 0; i < 3; ++i) {
-                p.emission[i] = o->emissionColor[i]; p.medium[i] = o->mediumColor[i]; p.background[i] = o->backgroundColor[i];
-            }
             p.round_max = tune_int("VR_TUNE_ROUND_MAX", VR_ROUND_MAX);
             p.round_events = tune_int("VR_TUNE_ROUND_EVENTS", VR_ROUND_EVENTS);
             // typical free path (index units) well under a voxel: remember each voxel's t-interval

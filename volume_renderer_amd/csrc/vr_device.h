@@ -83,8 +83,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     for (int r = 0; r < VR_PHILOX_ROUNDS; ++r) {
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
         const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        // three-way xor in one v_bitop3_b32 (truth table 0x96)
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
         c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -187,20 +188,21 @@ __device__ __forceinline__ float grid_fetch(const GridDev& g, f3 p, VoxelCache& 
 // ---- runs of empty-space steps ---------------------------------------------------------------
 // In a voxel with sigma <= 0 the reference's walks only do `tFar += step` with a constant step and
 // no random draw (IntegratorRatioTracking.cpp:84-96, :251-263; IntegratorDeltaTracking.cpp:70-82).
-// empty_run returns how many of those iterations (k >= 1) can be taken at once while every lookup
-// position stays inside a box — the current voxel, or its whole 8^3 brick when the brick's majorant
-// says it is empty; the caller passes t_safe = min(exit parameter of the shrunk box, t1) — and
-// every new t stays <= t1, and advances t exactly as k
-// sequential float additions would:  inside one binade [2^e, 2^(e+1)) a float is m * 2^(e-23)
-// with integer m, and fl(t + step) = t + q * 2^(e-23) with q = step / 2^(e-23) rounded to nearest
-// (ties are not handled here: they fall back to a single step), so k additions add k*q to the
-// integer bit pattern of t.  The box is shrunk by `slack` on every side, which covers the rounding
-// of fmaf(t, dir, eye) and of the exit-distance estimate; estimates only ever make k smaller.
+// empty_run takes as many of those iterations at once as START inside a box — the current voxel, or
+// its whole 8^3 brick when the brick's majorant says it is empty; the caller passes t_safe =
+// min(exit parameter of the shrunk box, t1) — and returns their number (>= 1).  All but the last
+// also END inside the box (and at t <= t1, so none of them is the walk's last); the last one is an
+// ordinary float addition that may leave it.  t advances exactly as that many sequential float
+// additions would:  inside one binade [2^e, 2^(e+1)) a float is m * 2^(e-23) with integer m, and
+// fl(t + step) = t + q * 2^(e-23) with q = step / 2^(e-23) rounded to nearest (ties are not
+// handled here: they fall back to a single step), so k additions add k*q to the integer bit
+// pattern of t.  The box is shrunk by `slack` on every side, which covers the rounding of
+// fmaf(t, dir, eye) and of the exit-distance estimate; estimates only ever make the run shorter.
 __device__ __forceinline__ uint32_t empty_run(float& t, float t_safe, float step)
 {
     const uint32_t tb = __float_as_uint(t);
     const uint32_t et = tb >> 23;                                  // t > 0: sign bit clear
-    uint32_t k = 1;
+    uint32_t k = 0;
     if (t_safe > t && et >= 24u && et < 254u) {
         const float x = step * __uint_as_float((277u - et) << 23); // step / ulp(t), exact
         const float xf = floorf(x);
@@ -213,15 +215,16 @@ __device__ __forceinline__ uint32_t empty_run(float& t, float t_safe, float step
             const float k1 = floorf((t_safe - t) * __builtin_amdgcn_rcpf(qu) * 0.999999f) - 1.0f;
             const float k2 = floorf((float)(0x7fffffu - (tb & 0x7fffffu)) * rq * 0.999999f) - 1.0f;
             const float kf = fminf(fminf(k1, k2), 65536.0f);
-            if (kf >= 2.0f) {
+            if (kf >= 1.0f) {
                 k = (uint32_t)kf;
                 t = __uint_as_float(tb + k * (uint32_t)qf);
-                return k;
             }
         }
     }
+    // the k steps above all START and END inside the box; one more ordinary step starts inside it
+    // (same sigma <= 0) and may end anywhere: the caller looks the new position up as usual
     t += step;
-    return 1;
+    return k + 1;
 }
 
 __device__ __forceinline__ float grid_value_nocache(const GridDev& g, f3 p)

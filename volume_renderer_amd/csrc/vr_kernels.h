@@ -61,13 +61,15 @@ struct TrackCold {
     float     bmin[3], bmax1[3];     // float(bbox.min), float(bbox.max + 1)
     float     g;
     float     light[3], light_color[3];
+    float     emission[3], medium[3], background[3];
     uint32_t  max_depth;
+    GridDev   temperature;
 };
 // Kernel argument: what the step loop reads.
 struct TrackParams {
     const TrackCold* cold;
     WorkDev   work;
-    GridDev   density, temperature;
+    GridDev   density;
     const float* majorant;           // per-brick max of the density grid
     int32_t   has_temperature;
     int32_t   use_span;              // steps are much shorter than a voxel: remember the voxel's t-interval
@@ -75,7 +77,6 @@ struct TrackParams {
     float     sigma_a, sigma_s, sigma_maj;
     float     t_min, t_max, step_mult;
     float     light_mult, shadow_mult;
-    float     emission[3], medium[3], background[3];
 };
 
 // primary ray of (abs column i, abs row j, sub-sample s)                  BaseIntegrator.cpp:35-64
@@ -120,7 +121,11 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 // events start their shadow walk, finished shadow walks add the light and pick the new direction,
 // finished paths store their sample and take the next work item.  A lane that meets an event waits
 // (a few iterations) for the phase instead of dragging the whole wave through the long, rare code.
-enum { ST_NEED = 0, ST_WALK = 1, ST_SCATTER = 2, ST_SHADOW_DONE = 3, ST_FINISHED = 4, ST_EXHAUSTED = 5 };
+enum {
+    ST_NEED = 0, ST_WALK = 1, ST_EXHAUSTED = 2,
+    // events, served by the event phase (every state >= ST_SCATTER)
+    ST_SCATTER = 3, ST_SHADOW_DONE = 4, ST_FINISHED = 5, ST_ESCAPED = 6, ST_ABSORBED = 7
+};
 #define VR_ROUND_MAX 24      // step-loop trips before the event phase runs regardless
 #define VR_ROUND_EVENTS 6    // ... or as soon as this many lanes wait for it
 
@@ -154,21 +159,21 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
     float    T = 1.0f, Tsh = 1.0f;      // data->transmission, shadow-walk transmission
     int      depth_remaining = 0;
     f3       scatter_p = mk3(0, 0, 0);  // iRay(tFar) of the pending scatter event
-    float    scatter_len = 0;           // its pathLength
+    float    scatter_len = 0;           // its pathLength (ST_ABSORBED: mu_a of the absorbing step)
     uint32_t rng_pixel = 0, rng_sample = 0, rng_tag = 0, rng_step = 0;   // Philox counter (vr_device.h)
     // density at iRay(tFar), fetched at the END of the previous trip so that its latency hides
     // behind the loop overhead and the next trip's Philox block
     float    cur_val = 0.0f;
     uint32_t cur_off = 0xffffffffu;     // its voxel offset (0xffffffff: outside the bbox)
     float    t_span = 0.0f;             // while t < t_span the walk is provably still inside that voxel
-    float    t_brick = 0.0f;            // same for the voxel's 8^3 brick
-    uint32_t brick_id = 0xffffffffu;    // brick of that voxel and its majorant (fetched with the voxel)
-    float    brick_major = 1.0f;
+    float    brick_major = 1.0f;        // majorant of that voxel's 8^3 brick (fetched with the voxel)
     unsigned long long n_lookups = 0;
     uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0;
     unsigned long long w_trips = 0, w_trip_lanes = 0, w_phases = 0;   // wave-uniform divergence counters
 
-    // value at iRay(t) for the coming trip (nearest voxel by floor, background outside)
+    // value at iRay(t) for the coming trip (nearest voxel by floor, background outside).  Results
+    // are collected in locals and assigned once at the end: every state variable is then written on
+    // every path, which keeps them all in registers.
     auto prefetch = [&]() {
         if (p.use_span && t < t_span) return;                  // same voxel, nothing to do
         const f3 q = ray_at(eye, dir, t);
@@ -176,35 +181,72 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
         const int32_t i = (int32_t)fx - p.density.min[0], j = (int32_t)fy - p.density.min[1], k = (int32_t)fz - p.density.min[2];
         const bool in = (uint32_t)i < (uint32_t)p.density.dim[0] && (uint32_t)j < (uint32_t)p.density.dim[1] &&
                         (uint32_t)k < (uint32_t)p.density.dim[2];
-        if (!in) { cur_val = p.density.background; cur_off = 0xffffffffu; t_span = t; return; }
-        const uint32_t off = brick_offset(p.density, (uint32_t)i, (uint32_t)j, (uint32_t)k);
-        if (off != cur_off) { cur_val = p.density.bricks[off]; cur_off = off; }
-        if (SKIP && (off >> 9) != brick_id) { brick_id = off >> 9; brick_major = p.majorant[brick_id]; }
-        if (p.use_span || SKIP) {
-            // exit parameters of the voxel, and of its brick, both shrunk by `slack` on every side
-            // (see empty_run)
-            const float slack = 0.01f;
-            const float bx = (float)(p.density.min[0] + (i & ~7)), by = (float)(p.density.min[1] + (j & ~7)),
-                        bz = (float)(p.density.min[2] + (k & ~7));
-            const bool  gx = dir.x > 0, gy = dir.y > 0, gz = dir.z > 0;
-            const float vx = (gx ? fx + (1.0f - slack) : fx + slack) - eye.x, wx = (gx ? bx + (8.0f - slack) : bx + slack) - eye.x;
-            const float vy = (gy ? fy + (1.0f - slack) : fy + slack) - eye.y, wy = (gy ? by + (8.0f - slack) : by + slack) - eye.y;
-            const float vz = (gz ? fz + (1.0f - slack) : fz + slack) - eye.z, wz = (gz ? bz + (8.0f - slack) : bz + slack) - eye.z;
-            const bool  nx = dir.x != 0, ny = dir.y != 0, nz = dir.z != 0;
-            t_span = fminf(fminf(nx ? vx * inv.x : VR_FLT_MAX, ny ? vy * inv.y : VR_FLT_MAX), nz ? vz * inv.z : VR_FLT_MAX);
-            if (SKIP) t_brick = fminf(fminf(nx ? wx * inv.x : VR_FLT_MAX, ny ? wy * inv.y : VR_FLT_MAX), nz ? wz * inv.z : VR_FLT_MAX);
+        float    n_val = p.density.background, n_span = t, n_major = brick_major;
+        uint32_t n_off = 0xffffffffu;
+        if (in) {
+            n_off = brick_offset(p.density, (uint32_t)i, (uint32_t)j, (uint32_t)k);
+            n_val = cur_val;
+            if (n_off != cur_off) n_val = p.density.bricks[n_off];
+            if (SKIP && (cur_off == 0xffffffffu || (n_off >> 9) != (cur_off >> 9))) n_major = p.majorant[n_off >> 9];
+            if (p.use_span || SKIP) {
+                // ray parameter at which the walk leaves the voxel shrunk by `slack` on every side (see empty_run)
+                const float slack = 0.01f;
+                const float vx = (dir.x > 0 ? fx + (1.0f - slack) : fx + slack) - eye.x;
+                const float vy = (dir.y > 0 ? fy + (1.0f - slack) : fy + slack) - eye.y;
+                const float vz = (dir.z > 0 ? fz + (1.0f - slack) : fz + slack) - eye.z;
+                n_span = fminf(fminf(dir.x != 0 ? vx * inv.x : VR_FLT_MAX, dir.y != 0 ? vy * inv.y : VR_FLT_MAX),
+                               dir.z != 0 ? vz * inv.z : VR_FLT_MAX);
+            }
         }
+        cur_val = n_val; cur_off = n_off; t_span = n_span; brick_major = n_major;
+    };
+    // same bound for the 8^3 brick around iRay(t); only needed when that brick is empty
+    auto brick_span = [&]() -> float {
+        const f3 q = ray_at(eye, dir, t);
+        const float slack = 0.01f;
+        // brick origin: floor to a multiple of 8 relative to bbox.min (a multiple of 8 voxels from it)
+        const float ox = (float)p.density.min[0], oy = (float)p.density.min[1], oz = (float)p.density.min[2];
+        const float bx = ox + 8.0f * floorf((floorf(q.x) - ox) * 0.125f);
+        const float by = oy + 8.0f * floorf((floorf(q.y) - oy) * 0.125f);
+        const float bz = oz + 8.0f * floorf((floorf(q.z) - oz) * 0.125f);
+        const float wx = (dir.x > 0 ? bx + (8.0f - slack) : bx + slack) - eye.x;
+        const float wy = (dir.y > 0 ? by + (8.0f - slack) : by + slack) - eye.y;
+        const float wz = (dir.z > 0 ? bz + (8.0f - slack) : bz + slack) - eye.z;
+        return fminf(fminf(dir.x != 0 ? wx * inv.x : VR_FLT_MAX, dir.y != 0 ? wy * inv.y : VR_FLT_MAX),
+                     dir.z != 0 ? wz * inv.z : VR_FLT_MAX);
     };
     auto set_ray = [&](f3 e, f3 d, float a, float b) {
         eye = e; dir = d; t = a; t1 = b;
         inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
         t_span = a;   // force a lookup
+        cur_off = 0xffffffffu;
         prefetch();
     };
 
     for (;;) {
         // =========================== event phase ===========================
         w_phases++;
+        // (0) walks that escaped or were absorbed add their constant colour
+        if (__any(st >= ST_ESCAPED)) {
+            if (st >= ST_ESCAPED) {
+                const TrackCold* c = opaque(p.cold);
+                if (st == ST_ESCAPED) {
+                    // survivor: radiance + background * transmission            IntegratorRatioTracking.cpp:208 (delta :175)
+                    const f3 bg = mk3(c->background[0], c->background[1], c->background[2]);
+                    radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, T) : bg);
+                } else {
+                    const f3 medium = mk3(c->medium[0], c->medium[1], c->medium[2]);
+                    if (INTEG == INTEG_RATIO) {                                   // :127-131
+                        radiance = add3(radiance, scale3(medium, T));
+                    } else {                                                      // delta :101-113
+                        if (p.has_temperature)
+                            radiance = add3(radiance, scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), scatter_len));
+                        radiance = add3(radiance, medium);
+                    }
+                }
+                st = ST_FINISHED;
+            }
+        }
         // (1) scatter events of the ratio tracker start their shadow walk        IntegratorRatioTracking.cpp:213-234
         if (INTEG == INTEG_RATIO && __any(st == ST_SCATTER)) {
             if (st == ST_SCATTER) {
@@ -250,7 +292,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                 } else if (depth_remaining <= 0) {
                     // `while (... && depthRemaining > 0)`: out of scatter budget, the walk ends as
                     // escaped                                                            :55, :208 (delta :54, :175)
-                    const f3 bg = mk3(p.background[0], p.background[1], p.background[2]);
+                    const f3 bg = mk3(c->background[0], c->background[1], c->background[2]);
                     radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, T) : bg);
                     st = ST_FINISHED;
                 } else {
@@ -300,7 +342,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                     float c0 = length * 1e-5f, c1 = VR_FLT_MAX;
                     if (!ray_clip(ieye, ndir, c0, c1, c->bmin, c->bmax1) || c->max_depth == 0) {
                         // missed the grid (:37-39), or a zero scatter budget: the loop never runs (:55, :208)
-                        store_sample(p.work.samples, item, mk3(p.background[0], p.background[1], p.background[2]));
+                        store_sample(p.work.samples, item, mk3(c->background[0], c->background[1], c->background[2]));
                     } else {
                         st = ST_WALK; shadow = false;
                         t0 = c0;
@@ -308,7 +350,6 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                         T = 1.0f;
                         depth_remaining = (int)c->max_depth;
                         rng_pixel = (cj << 16) | ci; rng_sample = s; rng_tag = 0; rng_step = 0;
-                        cur_off = 0xffffffffu;
                         set_ray(ieye, ndir, c0, c1);
                     }
                 }
@@ -358,7 +399,8 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                         len = in_shadow ? tmin * 100 : tmin * 10;                             // :252 / :85
                         if (SKIP && cur_off != 0xffffffffu) {
                             // an empty brick (majorant <= 0) is crossed in one run, else this voxel
-                            const float t_safe = (brick_major <= 0.0f && mult >= 0.0f) ? t_brick : t_span;
+                            float t_safe = t_span;
+                            if (brick_major <= 0.0f && mult >= 0.0f) t_safe = brick_span();
                             krun = empty_run(t, fminf(t_safe, t1), len);
                         } else {
                             t += len;
@@ -370,13 +412,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                     // rest of this iteration and the next Philox block run while it is in flight
                     if (t <= t1) prefetch();
                     if (t > t1) {                                                             // :91 / :258
-                        if (in_shadow) { st = ST_SHADOW_DONE; }                               // returns transmission
-                        else {
-                            // survivor: radiance + background * transmission                 :208 (delta :175)
-                            const f3 bg = mk3(p.background[0], p.background[1], p.background[2]);
-                            radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, T) : bg);
-                            st = ST_FINISHED;
-                        }
+                        st = in_shadow ? ST_SHADOW_DONE : ST_ESCAPED;                         // shadow walk returns its transmission
                     } else if (sigma > 0.0f) {
                         if (in_shadow) {
                             Tsh *= M::exp_(-(len)*mu_t);                                      // :266-269
@@ -394,10 +430,11 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                             if (INTEG == INTEG_RATIO) T = T * M::exp_(-(len)*mu_t);           // :103-105
                             const float sample = in_range(w2, 0.0f, 1.0f);                    // :108
                             if (INTEG == INTEG_RATIO && p.has_temperature) {                  // :110-122
-                                const float emission = grid_value_nocache(p.temperature, ray_at(eye, dir, t));
+                                const TrackCold* c = opaque(p.cold);
+                                const float emission = grid_value_nocache(c->temperature, ray_at(eye, dir, t));
                                 n_lookups++;
                                 if (emission > 0.0f) {
-                                    f3 e = scale3(mk3(p.emission[0], p.emission[1], p.emission[2]), T * mu_a);
+                                    f3 e = scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), T * mu_a);
                                     e = scale3(e, emission);
                                     e = scale3(e, len);
                                     radiance = add3(radiance, e);
@@ -406,16 +443,10 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                             if (sample < pNull) {
                                 // null collision
                             } else if (sample < pNull + pA) {
-                                if (INTEG == INTEG_RATIO) {                                   // :127-131
-                                    radiance = add3(radiance, scale3(mk3(p.medium[0], p.medium[1], p.medium[2]), T));
-                                } else {                                                      // delta :101-113
-                                    if (p.has_temperature) {
-                                        n_lookups++;   // accEmission.getValue, result unused (:103)
-                                        radiance = add3(radiance, scale3(mk3(p.emission[0], p.emission[1], p.emission[2]), mu_a));
-                                    }
-                                    radiance = add3(radiance, mk3(p.medium[0], p.medium[1], p.medium[2]));
-                                }
-                                st = ST_FINISHED;
+                                // absorption: the medium colour is added in the event phase  :127-131 (delta :101-113)
+                                if (INTEG == INTEG_DELTA && p.has_temperature) n_lookups++;   // accEmission.getValue, result unused (delta :103)
+                                scatter_len = mu_a;
+                                st = ST_ABSORBED;
                             } else {
                                 // scattering                                                :133-191 (delta :115-158)
                                 depth_remaining--;                                            // :136 (the `< 0` test never fires)
@@ -433,7 +464,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
             // leave for the event phase once enough lanes wait for it, or none walks any more
             const int n_walk = __popcll(__ballot(st == ST_WALK));
             w_trips++; w_trip_lanes += (unsigned)n_walk;
-            const int n_event = __popcll(__ballot(st == ST_SCATTER || st == ST_SHADOW_DONE || st == ST_FINISHED));
+            const int n_event = __popcll(__ballot(st >= ST_SCATTER));
             if (n_event >= p.round_events || n_walk == 0) break;
         }
     }
