@@ -190,20 +190,24 @@ void vro_minstd_canonical_double(uint32_t* state, double* out)
 }
 
 /* Philox stream layout (the GPU path's; no reference counterpart):
- *   counter = (pixel, sample, tag, step)   key = 64-bit seed
+ *   counter = (pixel, sample, tag, index)   key = 64-bit seed
  *   pixel = (row << 16) | column (absolute), tag = scatter count so far, | 0x80000000 inside the
- *   shadow walk of that scatter event, | 0x40000000 for the direction sample of that event;
- *   step = iteration index of the walk since the stream began.  One block per iteration:
- *   word 0 = Russian roulette at the loop top, word 1 = free path, word 2 = collision type
- *   (camera walk) or roulette (shadow walk).  A step's draws therefore do not depend on how many
- *   draws earlier steps made, which lets the GPU take runs of empty-space steps at once.
+ *   shadow walk of that scatter event.  Iteration `step` of a walk (every trip through the
+ *   reference's while loop counts, empty-space steps included) draws from block index = step / 2:
+ *   words (0,1) when step is even, (2,3) when it is odd; first word = free path, second =
+ *   collision type (camera walk) or roulette (shadow walk); both use the upper 24 bits.  The
+ *   camera walk's Russian roulette at the loop top draws 16 bits from the low bytes of the same
+ *   two words.  Side stream: tag | 0x40000000, index 0: words (0,1) = the direction sample of
+ *   that scatter event.
+ *   A step's draws therefore do not depend on how many draws earlier steps made, which lets the
+ *   GPU take runs of empty-space steps at once and walk two iterations on one block.
  * In VRO_RNG_REFERENCE mode every draw is the next RandomGenerator::getFloat of the chunk's
  * mt19937, in the reference's call order. */
 typedef struct vro_rng {
     int      mode;
     uint32_t key[2];
     uint32_t pixel, sample, tag, step, cur;
-    uint32_t blk[4];
+    uint32_t blk[4], blk_tag, blk_index;
     int      blk_valid;
     uint32_t saved_tag, saved_step;
     uint32_t* mt;         /* 625 words, owned by the row chunk */
@@ -212,11 +216,12 @@ typedef struct vro_rng {
 
 static inline float unit24(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
-static const uint32_t* rng_block(vro_rng* g)
+static const uint32_t* rng_block(vro_rng* g, uint32_t tag, uint32_t index)
 {
-    if (!g->blk_valid) {
-        uint32_t ctr[4] = { g->pixel, g->sample, g->tag, g->cur };
+    if (!g->blk_valid || g->blk_tag != tag || g->blk_index != index) {
+        uint32_t ctr[4] = { g->pixel, g->sample, tag, index };
         vro_philox4x32_10(ctr, g->key, g->blk);
+        g->blk_tag = tag; g->blk_index = index;
         g->blk_valid = 1;
     }
     return g->blk;
@@ -233,25 +238,25 @@ static void rng_begin_path(vro_rng* g, uint32_t i, uint32_t j, uint32_t s)
 static void rng_begin_step(vro_rng* g)
 {
     g->cur = g->step++;
-    g->blk_valid = 0;
 }
 /* getFloat(0, 1) of the roulette at the loop top (REF IntegratorRatioTracking.cpp:60) */
 static float rng_roulette(vro_rng* g)
 {
     if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, 0.0f, 1.0f);
-    return (unit24(rng_block(g)[0]) * (1.0f - 0.0f)) + 0.0f;
+    const uint32_t* w = rng_block(g, g->tag, g->cur >> 1) + (g->cur & 1u) * 2u;
+    return (float)(((w[0] & 0xffu) << 8) | (w[1] & 0xffu)) * (1.0f / 65536.0f);
 }
 /* getFloat(0.00001f, 1.0f) of the free-path sample (REF :80, :247) */
 static float rng_free_path(vro_rng* g)
 {
     if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, 0.00001f, 1.0f);
-    return (unit24(rng_block(g)[1]) * (1.0f - 0.00001f)) + 0.00001f;
+    return (unit24(rng_block(g, g->tag, g->cur >> 1)[(g->cur & 1u) * 2u]) * (1.0f - 0.00001f)) + 0.00001f;
 }
 /* getFloat(0, 1) of the collision type (REF :108) / of the shadow walk's roulette (REF :275) */
 static float rng_event(vro_rng* g)
 {
     if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, 0.0f, 1.0f);
-    return (unit24(rng_block(g)[2]) * (1.0f - 0.0f)) + 0.0f;
+    return (unit24(rng_block(g, g->tag, g->cur >> 1)[(g->cur & 1u) * 2u + 1u]) * (1.0f - 0.0f)) + 0.0f;
 }
 /* the two getFloat(0, 0.9999f) of sampleHenyeyGreenstein (REF Utils/DirectionSampler.cpp:43,58) */
 static void rng_direction(vro_rng* g, float* xi1, float* xi2)
@@ -292,13 +297,13 @@ static void rng_pop_shadow(vro_rng* g)
 static double rng_march_jitter(vro_rng* g, uint32_t n)
 {
     if (g->mode == VRO_RNG_REFERENCE) { double d; vro_minstd_canonical_double(g->jitter, &d); return d; }
-    g->cur = n; g->blk_valid = 0;
-    return (double)unit24(rng_block(g)[0]);
+    g->cur = n;
+    return (double)unit24(rng_block(g, 0u, n)[0]);
 }
 static float rng_march_roulette(vro_rng* g)
 {
     if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, 0, 1);
-    return (unit24(rng_block(g)[1]) * (1.0f - 0.0f)) + 0.0f;
+    return (unit24(rng_block(g, 0u, g->cur)[1]) * (1.0f - 0.0f)) + 0.0f;
 }
 
 /* ------------------------------------------------------------------------------------ */

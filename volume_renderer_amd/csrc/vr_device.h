@@ -65,14 +65,18 @@ struct Math<false> {
 // ---- Philox4x32-10 (Salmon et al. 2011) ------------------------------------------------------
 // Replaces RandomGenerator (Utils/RandomGenerator.cpp:4-14): only the ranges of its draws are
 // contract.  Stream layout (mirrored by the oracle's vro_rng):
-//   counter = (pixel, sample, tag, step), key = 64-bit seed
+//   counter = (pixel, sample, tag, index), key = 64-bit seed
 //   pixel = (row << 16) | column in absolute image coordinates, so a pixel's stream does not depend
 //   on crop, row partition or GPU count; tag = scatter count so far, | 0x80000000 inside the shadow
-//   walk of that scatter event, | 0x40000000 for its direction sample; step = iteration index of
-//   the walk.  ONE block per iteration: word 0 = roulette at the loop top, word 1 = free path,
-//   word 2 = collision type (camera walk) / roulette (shadow walk).
-// A step's draws do not depend on how many draws earlier steps made: every lane of a wave
-// generates its block at the same instruction, and runs of empty-space steps can be taken at once.
+//   walk of that scatter event.  Iteration `step` of a walk (counted as the reference iterates,
+//   empty-space steps included) draws from block index = step / 2: words (0,1) when step is even,
+//   (2,3) when it is odd; first word = free path, second = collision type (camera walk) or
+//   roulette (shadow walk); both use the upper 24 bits.  The camera walk's roulette at the loop
+//   top (rare) draws 16 bits from the low bytes of the same two words.  Side stream:
+//   tag | 0x40000000, index 0: words (0,1) = the direction sample of that scatter event.
+// A step's draws do not depend on how many draws earlier steps made, so runs of empty-space steps
+// can be taken at once; the tracking kernel keeps every lane on an even step at the top of a trip
+// (runs are odd), generates one block per trip and walks two iterations on it.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
 {
@@ -94,6 +98,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // uniform in [0,1) with 24 bits, then RandomGenerator::getFloat(lo, hi) = lo + u*(hi-lo)
 __device__ __forceinline__ float unit24(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 __device__ __forceinline__ float in_range(uint32_t w, float lo, float hi) { return (unit24(w) * (hi - lo)) + lo; }
+// the camera walk's roulette draw: 16 bits in [0,1) from the low bytes of the iteration's two words
+// (unit24 uses the upper 24 bits of each)
+__device__ __forceinline__ float roulette16(uint32_t w_path, uint32_t w_event)
+{
+    return (float)(((w_path & 0xffu) << 8) | (w_event & 0xffu)) * (1.0f / 65536.0f);
+}
 
 // ---- nanovdb::Ray<float> ----------------------------------------------------------------------
 struct Ray {
@@ -190,7 +200,7 @@ __device__ __forceinline__ float grid_fetch(const GridDev& g, f3 p, VoxelCache& 
 // no random draw (IntegratorRatioTracking.cpp:84-96, :251-263; IntegratorDeltaTracking.cpp:70-82).
 // empty_run takes as many of those iterations at once as START inside a box — the current voxel, or
 // its whole 8^3 brick when the brick's majorant says it is empty; the caller passes t_safe =
-// min(exit parameter of the shrunk box, t1) — and returns their number (>= 1).  All but the last
+// min(exit parameter of the shrunk box, t1) — and returns their number (>= 1, always odd).  All but the last
 // also END inside the box (and at t <= t1, so none of them is the walk's last); the last one is an
 // ordinary float addition that may leave it.  t advances exactly as that many sequential float
 // additions would:  inside one binade [2^e, 2^(e+1)) a float is m * 2^(e-23) with integer m, and
@@ -215,8 +225,8 @@ __device__ __forceinline__ uint32_t empty_run(float& t, float t_safe, float step
             const float k1 = floorf((t_safe - t) * __builtin_amdgcn_rcpf(qu) * 0.999999f) - 1.0f;
             const float k2 = floorf((float)(0x7fffffu - (tb & 0x7fffffu)) * rq * 0.999999f) - 1.0f;
             const float kf = fminf(fminf(k1, k2), 65536.0f);
-            if (kf >= 1.0f) {
-                k = (uint32_t)kf;
+            if (kf >= 2.0f) {
+                k = (uint32_t)kf & ~1u;   // even, so that the run as a whole (k + 1) is odd: see the Philox layout
                 t = __uint_as_float(tb + k * (uint32_t)qf);
             }
         }

@@ -146,13 +146,22 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
     typedef Math<EXACT> M;
     const int      lane = threadIdx.x & 63;
     const uint32_t k0 = p.work.key0, k1 = p.work.key1;
+    // FAST arithmetic: constants of the step loop folded once (wave-uniform)
+    const float fast_c_ln = -0.6931471805599453f * p.step_mult;                 // len = log2(u) * fast_c_ln / denominator
+    const float fast_c_cam = fast_c_ln / p.sigma_maj;
+    const float fast_sig_t = p.sigma_a + p.sigma_s;                             // mu_t = sigma * fast_sig_t
+    const float fast_sig_t2 = -(p.sigma_a + p.sigma_s) * 1.4426950408889634f;   // exp(-len mu_t) = exp2(len * sigma * fast_sig_t2)
+    const float fast_pa24 = p.sigma_a / p.sigma_maj * 16777216.0f, fast_ps24 = p.sigma_s / p.sigma_maj * 16777216.0f;
 
     // ---- per-lane path state (HandleIntersectionData, BaseIntegrator.h:21-50) ----
     uint32_t st = ST_NEED;
     bool     shadow = false;            // walking directLightningRayMarch
     uint32_t item = 0;
     f3       eye = mk3(0, 0, 0), dir = mk3(0, 0, 1);   // current index-space ray (camera walk or shadow walk)
-    f3       inv = mk3(0, 0, 1);        // 1/dir, for the voxel-span and empty-run estimates only
+    // voxel-span / empty-run estimates only: 1/dir (NaN where dir == 0: fminf then ignores that axis)
+    // and, per axis, (dir > 0 ? 1 - slack : slack) - eye, so that the ray leaves the shrunk voxel
+    // whose corner is f at t = (f + span_off) * inv
+    f3       inv = mk3(0, 0, 1), span_off = mk3(0, 0, 0);
     float    t = 0, t1 = 0, t0 = 0;     // tFar, iRay.t1(), iRay.t0()
     f3       wdir = mk3(0, 0, 1);       // data->rayDirection
     f3       radiance = mk3(0, 0, 0);   // data->radiance / result
@@ -188,36 +197,29 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
             n_val = cur_val;
             if (n_off != cur_off) n_val = p.density.bricks[n_off];
             if (SKIP && (cur_off == 0xffffffffu || (n_off >> 9) != (cur_off >> 9))) n_major = p.majorant[n_off >> 9];
-            if (p.use_span || SKIP) {
+            if (p.use_span || SKIP)
                 // ray parameter at which the walk leaves the voxel shrunk by `slack` on every side (see empty_run)
-                const float slack = 0.01f;
-                const float vx = (dir.x > 0 ? fx + (1.0f - slack) : fx + slack) - eye.x;
-                const float vy = (dir.y > 0 ? fy + (1.0f - slack) : fy + slack) - eye.y;
-                const float vz = (dir.z > 0 ? fz + (1.0f - slack) : fz + slack) - eye.z;
-                n_span = fminf(fminf(dir.x != 0 ? vx * inv.x : VR_FLT_MAX, dir.y != 0 ? vy * inv.y : VR_FLT_MAX),
-                               dir.z != 0 ? vz * inv.z : VR_FLT_MAX);
-            }
+                n_span = fminf(fminf((fx + span_off.x) * inv.x, (fy + span_off.y) * inv.y), (fz + span_off.z) * inv.z);
         }
         cur_val = n_val; cur_off = n_off; t_span = n_span; brick_major = n_major;
     };
     // same bound for the 8^3 brick around iRay(t); only needed when that brick is empty
     auto brick_span = [&]() -> float {
         const f3 q = ray_at(eye, dir, t);
-        const float slack = 0.01f;
         // brick origin: floor to a multiple of 8 relative to bbox.min (a multiple of 8 voxels from it)
         const float ox = (float)p.density.min[0], oy = (float)p.density.min[1], oz = (float)p.density.min[2];
-        const float bx = ox + 8.0f * floorf((floorf(q.x) - ox) * 0.125f);
-        const float by = oy + 8.0f * floorf((floorf(q.y) - oy) * 0.125f);
-        const float bz = oz + 8.0f * floorf((floorf(q.z) - oz) * 0.125f);
-        const float wx = (dir.x > 0 ? bx + (8.0f - slack) : bx + slack) - eye.x;
-        const float wy = (dir.y > 0 ? by + (8.0f - slack) : by + slack) - eye.y;
-        const float wz = (dir.z > 0 ? bz + (8.0f - slack) : bz + slack) - eye.z;
-        return fminf(fminf(dir.x != 0 ? wx * inv.x : VR_FLT_MAX, dir.y != 0 ? wy * inv.y : VR_FLT_MAX),
-                     dir.z != 0 ? wz * inv.z : VR_FLT_MAX);
+        const float bx = ox + 8.0f * floorf((floorf(q.x) - ox) * 0.125f) + (dir.x > 0 ? 7.0f : 0.0f);
+        const float by = oy + 8.0f * floorf((floorf(q.y) - oy) * 0.125f) + (dir.y > 0 ? 7.0f : 0.0f);
+        const float bz = oz + 8.0f * floorf((floorf(q.z) - oz) * 0.125f) + (dir.z > 0 ? 7.0f : 0.0f);
+        return fminf(fminf((bx + span_off.x) * inv.x, (by + span_off.y) * inv.y), (bz + span_off.z) * inv.z);
     };
     auto set_ray = [&](f3 e, f3 d, float a, float b) {
         eye = e; dir = d; t = a; t1 = b;
-        inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+        const float slack = 0.01f, nan = __builtin_nanf("");
+        inv = mk3(d.x != 0 ? __builtin_amdgcn_rcpf(d.x) : nan, d.y != 0 ? __builtin_amdgcn_rcpf(d.y) : nan,
+                  d.z != 0 ? __builtin_amdgcn_rcpf(d.z) : nan);
+        span_off = mk3((d.x > 0 ? 1.0f - slack : slack) - e.x, (d.y > 0 ? 1.0f - slack : slack) - e.y,
+                       (d.z > 0 ? 1.0f - slack : slack) - e.z);
         t_span = a;   // force a lookup
         cur_off = 0xffffffffu;
         prefetch();
@@ -358,104 +360,135 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
         if (!__any(st == ST_WALK)) break;   // every lane exhausted (events were all served above)
 
         // =========================== step loop ===========================
+        // One trip = one Philox block = TWO iterations of the reference's while loop: every iteration
+        // advances the walk's step index by an odd number (1, or an odd run of empty steps), so a
+        // trip starts on an even index, its first iteration draws words (0,1) of block index/2 and
+        // its second one words (2,3).
+        if (st == ST_WALK && rng_step > p.work.step_limit) { n_limit++; st = ST_FINISHED; }   // safety cap, once per round
 #pragma unroll 1
         for (int it = 0; it < p.round_max; ++it) {
-            if (st == ST_WALK) {
+            uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            if (st == ST_WALK) philox4x32_10(rng_pixel, rng_sample, rng_tag, rng_step >> 1, k0, k1, w0, w1, w2, w3);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (st != ST_WALK) continue;
+                const uint32_t w_path = half ? w2 : w0, w_event = half ? w3 : w1;
                 const bool in_shadow = (INTEG == INTEG_RATIO) && shadow;
-                // this iteration's random block; does not depend on the voxel still in flight
-                uint32_t w0, w1, w2, w3;
-                philox4x32_10(rng_pixel, rng_sample, rng_tag, rng_step, k0, k1, w0, w1, w2, w3);
 
                 // sigma = multiplier * acc.getValue(Coord::Floor(iRay(tFar)))                :71 / :238
                 const float mult = in_shadow ? p.shadow_mult : p.light_mult;
                 const float sigma = mult * cur_val;
-                bool walking = true;
 
-                if (rng_step > p.work.step_limit) { n_limit++; st = ST_FINISHED; walking = false; }
                 if (INTEG == INTEG_RATIO && !in_shadow && T < 0.05f) {
                     // Russian roulette on the camera walk     IntegratorRatioTracking.cpp:57-69
                     // (a path it ends does not count the lookup above, as in the reference)
                     const float q = 0.75f;
-                    if (in_range(w0, 0.0f, 1.0f) < q) T = 0.0f;
+                    if (roulette16(w_path, w_event) < q) T = 0.0f;
                     else T /= 1.0f - q;
-                    if (T <= 0.0f) { st = ST_FINISHED; walking = false; }
+                    if (T <= 0.0f) { st = ST_FINISHED; continue; }
                 }
 
-                if (walking) {
-                    const float mu_a = sigma * p.sigma_a;
-                    const float mu_s = sigma * p.sigma_s;
-                    const float mu_t = mu_a + mu_s;
-                    const float tmin = in_shadow ? p.t_min * 5 : p.t_min;                     // :216
-                    float    len;
-                    uint32_t krun = 1;
-                    if (sigma > 0.0f) {
-                        // free path: camera walk over the global majorant, shadow walk over mu_t   :80-82 / :247-249
+                const float tmin = in_shadow ? p.t_min * 5 : p.t_min;                         // :216
+                float    len;
+                uint32_t krun = 1;
+                if (sigma > 0.0f) {
+                    // free path: camera walk over the global majorant, shadow walk over mu_t   :80-82 / :247-249
+                    if (EXACT) {
+                        const float mu_t = sigma * p.sigma_a + sigma * p.sigma_s;
                         const float denom = in_shadow ? mu_t : p.sigma_maj;
-                        len = M::div_(-M::log_(in_range(w1, 0.00001f, 1.0f)), denom);
+                        len = M::div_(-M::log_(in_range(w_path, 0.00001f, 1.0f)), denom);
                         len *= p.step_mult;
                         len = clamp_lo_hi(tmin, p.t_max, len);
-                        t += len;                                                             // :88 / :255
                     } else {
-                        len = in_shadow ? tmin * 100 : tmin * 10;                             // :252 / :85
-                        if (SKIP && cur_off != 0xffffffffu) {
-                            // an empty brick (majorant <= 0) is crossed in one run, else this voxel
-                            float t_safe = t_span;
-                            if (brick_major <= 0.0f && mult >= 0.0f) t_safe = brick_span();
-                            krun = empty_run(t, fminf(t_safe, t1), len);
-                        } else {
-                            t += len;
-                        }
+                        // same quantities with the constants folded: -ln 2 * stepSizeMultiplier / denominator
+                        const float u = fmaf((float)(w_path >> 8), (1.0f - 0.00001f) / 16777216.0f, 0.00001f);
+                        const float c_cam = fast_c_cam;
+                        const float c = in_shadow ? fast_c_ln * __builtin_amdgcn_rcpf(sigma * fast_sig_t) : c_cam;
+                        len = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(u) * c, tmin, p.t_max);
                     }
-                    n_lookups += krun;
-                    rng_step += krun;
-                    // the next iteration's voxel, requested as early as its position is known; the
-                    // rest of this iteration and the next Philox block run while it is in flight
-                    if (t <= t1) prefetch();
-                    if (t > t1) {                                                             // :91 / :258
-                        st = in_shadow ? ST_SHADOW_DONE : ST_ESCAPED;                         // shadow walk returns its transmission
-                    } else if (sigma > 0.0f) {
-                        if (in_shadow) {
-                            Tsh *= M::exp_(-(len)*mu_t);                                      // :266-269
-                            if (Tsh < 0.05f) {                                                // :272-279
-                                const float q = 0.75f;
-                                if (in_range(w2, 0.0f, 1.0f) < q) Tsh = 0.0f;
-                                else Tsh /= 1.0f - q;
-                            }
-                            if (Tsh <= 0.0f) st = ST_SHADOW_DONE;                             // :281
-                        } else {
-                            const float pA = M::div_(mu_a, p.sigma_maj);                      // :98-100
+                    t += len;                                                                 // :88 / :255
+                } else {
+                    len = in_shadow ? tmin * 100 : tmin * 10;                                 // :252 / :85
+                    if (SKIP && cur_off != 0xffffffffu) {
+                        // an empty brick (majorant <= 0) is crossed in one run, else this voxel
+                        float t_safe = t_span;
+                        if (brick_major <= 0.0f && mult >= 0.0f) t_safe = brick_span();
+                        krun = empty_run(t, fminf(t_safe, t1), len);
+                    } else {
+                        t += len;
+                    }
+                }
+                n_lookups += krun;
+                rng_step += krun;
+                // the next iteration's voxel, requested as early as its position is known
+                if (t <= t1) prefetch();
+                if (t > t1) {                                                                 // :91 / :258
+                    st = in_shadow ? ST_SHADOW_DONE : ST_ESCAPED;                             // shadow walk returns its transmission
+                } else if (sigma > 0.0f) {
+                    // attenuation over the step: exp(-len * mu_t)                            :103-105 / :266-269
+                    float att = 1.0f, mu_a = 0.0f;
+                    if (EXACT) {
+                        mu_a = sigma * p.sigma_a;
+                        const float mu_t = mu_a + sigma * p.sigma_s;
+                        if (INTEG == INTEG_RATIO) att = M::exp_(-(len)*mu_t);
+                    } else {
+                        if (INTEG == INTEG_RATIO) att = __builtin_amdgcn_exp2f(len * (sigma * fast_sig_t2));
+                    }
+                    if (in_shadow) {
+                        Tsh *= att;
+                        if (Tsh < 0.05f) {                                                    // :272-279
+                            const float q = 0.75f;
+                            if (in_range(w_event, 0.0f, 1.0f) < q) Tsh = 0.0f;
+                            else Tsh /= 1.0f - q;
+                        }
+                        if (Tsh <= 0.0f) st = ST_SHADOW_DONE;                                 // :281
+                    } else {
+                        // collision type: null / absorption / scattering                     :98-100, :108
+                        bool is_null, is_absorb;
+                        if (EXACT) {
+                            const float mu_s = sigma * p.sigma_s;
+                            const float pA = M::div_(mu_a, p.sigma_maj);
                             const float pS = M::div_(mu_s, p.sigma_maj);
                             const float pn = 1 - pA - pS;
                             const float pNull = (0 < pn) ? pn : 0;
-                            if (INTEG == INTEG_RATIO) T = T * M::exp_(-(len)*mu_t);           // :103-105
-                            const float sample = in_range(w2, 0.0f, 1.0f);                    // :108
-                            if (INTEG == INTEG_RATIO && p.has_temperature) {                  // :110-122
-                                const TrackCold* c = opaque(p.cold);
-                                const float emission = grid_value_nocache(c->temperature, ray_at(eye, dir, t));
-                                n_lookups++;
-                                if (emission > 0.0f) {
-                                    f3 e = scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), T * mu_a);
-                                    e = scale3(e, emission);
-                                    e = scale3(e, len);
-                                    radiance = add3(radiance, e);
-                                }
+                            const float sample = in_range(w_event, 0.0f, 1.0f);
+                            is_null = sample < pNull;
+                            is_absorb = sample < pNull + pA;
+                        } else {
+                            // the same comparisons scaled by 2^24 (exact), against the raw 24-bit draw
+                            const float pA = sigma * fast_pa24, pS = sigma * fast_ps24;
+                            const float pNull = fmaxf(16777216.0f - pA - pS, 0.0f);
+                            const float sample = (float)(w_event >> 8);
+                            is_null = sample < pNull;
+                            is_absorb = sample < pNull + pA;
+                        }
+                        if (INTEG == INTEG_RATIO) T = T * att;
+                        if (INTEG == INTEG_RATIO && p.has_temperature) {                      // :110-122
+                            const TrackCold* c = opaque(p.cold);
+                            const float emission = grid_value_nocache(c->temperature, ray_at(eye, dir, t));
+                            n_lookups++;
+                            if (emission > 0.0f) {
+                                f3 e = scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), T * (sigma * p.sigma_a));
+                                e = scale3(e, emission);
+                                e = scale3(e, len);
+                                radiance = add3(radiance, e);
                             }
-                            if (sample < pNull) {
-                                // null collision
-                            } else if (sample < pNull + pA) {
-                                // absorption: the medium colour is added in the event phase  :127-131 (delta :101-113)
-                                if (INTEG == INTEG_DELTA && p.has_temperature) n_lookups++;   // accEmission.getValue, result unused (delta :103)
-                                scatter_len = mu_a;
-                                st = ST_ABSORBED;
-                            } else {
-                                // scattering                                                :133-191 (delta :115-158)
-                                depth_remaining--;                                            // :136 (the `< 0` test never fires)
-                                n_scatter++;
-                                if (INTEG == INTEG_DELTA || T > 0.0f) {                       // :141
-                                    scatter_p = ray_at(eye, dir, t);                          // :162 (delta :130)
-                                    scatter_len = len;
-                                    st = INTEG == INTEG_DELTA ? ST_SHADOW_DONE : ST_SCATTER;
-                                }
+                        }
+                        if (is_null) {
+                            // null collision
+                        } else if (is_absorb) {
+                            // absorption: the medium colour is added in the event phase      :127-131 (delta :101-113)
+                            if (INTEG == INTEG_DELTA && p.has_temperature) n_lookups++;       // accEmission.getValue, result unused (delta :103)
+                            scatter_len = sigma * p.sigma_a;
+                            st = ST_ABSORBED;
+                        } else {
+                            // scattering                                                    :133-191 (delta :115-158)
+                            depth_remaining--;                                                // :136 (the `< 0` test never fires)
+                            n_scatter++;
+                            if (INTEG == INTEG_DELTA || T > 0.0f) {                           // :141
+                                scatter_p = ray_at(eye, dir, t);                              // :162 (delta :130)
+                                scatter_len = len;
+                                st = INTEG == INTEG_DELTA ? ST_SHADOW_DONE : ST_SCATTER;
                             }
                         }
                     }
