@@ -75,8 +75,8 @@ struct Math<false> {
 //   top (rare) draws 16 bits from the low bytes of the same two words.  Side stream:
 //   tag | 0x40000000, index 0: words (0,1) = the direction sample of that scatter event.
 // A step's draws do not depend on how many draws earlier steps made, so runs of empty-space steps
-// can be taken at once; the tracking kernel keeps every lane on an even step at the top of a trip
-// (runs are odd), generates one block per trip and walks two iterations on it.
+// can be taken at once; the tracking kernel generates one block per trip and walks up to two
+// iterations on it.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
 {
@@ -200,7 +200,7 @@ __device__ __forceinline__ float grid_fetch(const GridDev& g, f3 p, VoxelCache& 
 // no random draw (IntegratorRatioTracking.cpp:84-96, :251-263; IntegratorDeltaTracking.cpp:70-82).
 // empty_run takes as many of those iterations at once as START inside a box — the current voxel, or
 // its whole 8^3 brick when the brick's majorant says it is empty; the caller passes t_safe =
-// min(exit parameter of the shrunk box, t1) — and returns their number (>= 1, always odd).  All but the last
+// min(exit parameter of the shrunk box, t1) — and returns their number (>= 1).  All but the last
 // also END inside the box (and at t <= t1, so none of them is the walk's last); the last one is an
 // ordinary float addition that may leave it.  t advances exactly as that many sequential float
 // additions would:  inside one binade [2^e, 2^(e+1)) a float is m * 2^(e-23) with integer m, and
@@ -225,8 +225,8 @@ __device__ __forceinline__ uint32_t empty_run(float& t, float t_safe, float step
             const float k1 = floorf((t_safe - t) * __builtin_amdgcn_rcpf(qu) * 0.999999f) - 1.0f;
             const float k2 = floorf((float)(0x7fffffu - (tb & 0x7fffffu)) * rq * 0.999999f) - 1.0f;
             const float kf = fminf(fminf(k1, k2), 65536.0f);
-            if (kf >= 2.0f) {
-                k = (uint32_t)kf & ~1u;   // even, so that the run as a whole (k + 1) is odd: see the Philox layout
+            if (kf >= 1.0f) {
+                k = (uint32_t)kf;
                 t = __uint_as_float(tb + k * (uint32_t)qf);
             }
         }

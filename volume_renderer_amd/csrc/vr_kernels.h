@@ -360,19 +360,25 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
         if (!__any(st == ST_WALK)) break;   // every lane exhausted (events were all served above)
 
         // =========================== step loop ===========================
-        // One trip = one Philox block = TWO iterations of the reference's while loop: every iteration
-        // advances the walk's step index by an odd number (1, or an odd run of empty steps), so a
-        // trip starts on an even index, its first iteration draws words (0,1) of block index/2 and
-        // its second one words (2,3).
+        // One trip = one Philox block = up to TWO iterations of the reference's while loop: iteration
+        // `step` of a walk draws words (0,1) of block step/2 when step is even, words (2,3) when it
+        // is odd.  A lane that enters a trip on an even step can take both halves, one on an odd
+        // step only the first.  Few lanes are in empty space at any time but nearly every wave
+        // has one, so the empty-space code runs once per trip, after the two halves: a lane that
+        // finds sigma <= 0 sits out the rest of the trip and takes its run there.
         if (st == ST_WALK && rng_step > p.work.step_limit) { n_limit++; st = ST_FINISHED; }   // safety cap, once per round
 #pragma unroll 1
         for (int it = 0; it < p.round_max; ++it) {
             uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-            if (st == ST_WALK) philox4x32_10(rng_pixel, rng_sample, rng_tag, rng_step >> 1, k0, k1, w0, w1, w2, w3);
+            const uint32_t block = rng_step >> 1;
+            if (st == ST_WALK) philox4x32_10(rng_pixel, rng_sample, rng_tag, block, k0, k1, w0, w1, w2, w3);
+            bool empty = false;     // this lane's current iteration is an empty-space step, still to be taken
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                if (st != ST_WALK) continue;
-                const uint32_t w_path = half ? w2 : w0, w_event = half ? w3 : w1;
+                if (st != ST_WALK || empty || (half && (rng_step >> 1) != block)) continue;
+                // (the second half only ever sees odd steps)
+                const bool     odd = half || (rng_step & 1u);
+                const uint32_t w_path = odd ? w2 : w0, w_event = odd ? w3 : w1;
                 const bool in_shadow = (INTEG == INTEG_RATIO) && shadow;
 
                 // sigma = multiplier * acc.getValue(Coord::Floor(iRay(tFar)))                :71 / :238
@@ -387,113 +393,124 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                     else T /= 1.0f - q;
                     if (T <= 0.0f) { st = ST_FINISHED; continue; }
                 }
+                if (!(sigma > 0.0f)) { empty = true; continue; }
 
+                // free path: camera walk over the global majorant, shadow walk over mu_t   :80-82 / :247-249
                 const float tmin = in_shadow ? p.t_min * 5 : p.t_min;                         // :216
-                float    len;
-                uint32_t krun = 1;
-                if (sigma > 0.0f) {
-                    // free path: camera walk over the global majorant, shadow walk over mu_t   :80-82 / :247-249
-                    if (EXACT) {
-                        const float mu_t = sigma * p.sigma_a + sigma * p.sigma_s;
-                        const float denom = in_shadow ? mu_t : p.sigma_maj;
-                        len = M::div_(-M::log_(in_range(w_path, 0.00001f, 1.0f)), denom);
-                        len *= p.step_mult;
-                        len = clamp_lo_hi(tmin, p.t_max, len);
-                    } else {
-                        // same quantities with the constants folded: -ln 2 * stepSizeMultiplier / denominator
-                        const float u = fmaf((float)(w_path >> 8), (1.0f - 0.00001f) / 16777216.0f, 0.00001f);
-                        const float c_cam = fast_c_cam;
-                        const float c = in_shadow ? fast_c_ln * __builtin_amdgcn_rcpf(sigma * fast_sig_t) : c_cam;
-                        len = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(u) * c, tmin, p.t_max);
-                    }
-                    t += len;                                                                 // :88 / :255
+                float len;
+                if (EXACT) {
+                    const float mu_t = sigma * p.sigma_a + sigma * p.sigma_s;
+                    const float denom = in_shadow ? mu_t : p.sigma_maj;
+                    len = M::div_(-M::log_(in_range(w_path, 0.00001f, 1.0f)), denom);
+                    len *= p.step_mult;
+                    len = clamp_lo_hi(tmin, p.t_max, len);
                 } else {
-                    len = in_shadow ? tmin * 100 : tmin * 10;                                 // :252 / :85
-                    if (SKIP && cur_off != 0xffffffffu) {
-                        // an empty brick (majorant <= 0) is crossed in one run, else this voxel
-                        float t_safe = t_span;
-                        if (brick_major <= 0.0f && mult >= 0.0f) t_safe = brick_span();
-                        krun = empty_run(t, fminf(t_safe, t1), len);
-                    } else {
-                        t += len;
-                    }
+                    // same quantities with the constants folded: -ln 2 * stepSizeMultiplier / denominator
+                    const float u = fmaf((float)(w_path >> 8), (1.0f - 0.00001f) / 16777216.0f, 0.00001f);
+                    const float c = in_shadow ? fast_c_ln * __builtin_amdgcn_rcpf(sigma * fast_sig_t) : fast_c_cam;
+                    len = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(u) * c, tmin, p.t_max);
                 }
-                n_lookups += krun;
-                rng_step += krun;
-                // the next iteration's voxel, requested as early as its position is known
-                if (t <= t1) prefetch();
+                t += len;                                                                     // :88 / :255
+                n_lookups += 1;
+                rng_step += 1;
+                // the second iteration's voxel, requested as early as its position is known (the
+                // voxel for the next trip is requested after the runs below)
+                if (half == 0 && t <= t1) prefetch();
                 if (t > t1) {                                                                 // :91 / :258
                     st = in_shadow ? ST_SHADOW_DONE : ST_ESCAPED;                             // shadow walk returns its transmission
-                } else if (sigma > 0.0f) {
-                    // attenuation over the step: exp(-len * mu_t)                            :103-105 / :266-269
-                    float att = 1.0f, mu_a = 0.0f;
-                    if (EXACT) {
-                        mu_a = sigma * p.sigma_a;
-                        const float mu_t = mu_a + sigma * p.sigma_s;
-                        if (INTEG == INTEG_RATIO) att = M::exp_(-(len)*mu_t);
-                    } else {
-                        if (INTEG == INTEG_RATIO) att = __builtin_amdgcn_exp2f(len * (sigma * fast_sig_t2));
+                    continue;
+                }
+                // attenuation over the step: exp(-len * mu_t)                                :103-105 / :266-269
+                float att = 1.0f, mu_a = 0.0f;
+                if (EXACT) {
+                    mu_a = sigma * p.sigma_a;
+                    const float mu_t = mu_a + sigma * p.sigma_s;
+                    if (INTEG == INTEG_RATIO) att = M::exp_(-(len)*mu_t);
+                } else {
+                    if (INTEG == INTEG_RATIO) att = __builtin_amdgcn_exp2f(len * (sigma * fast_sig_t2));
+                }
+                if (in_shadow) {
+                    Tsh *= att;
+                    if (Tsh < 0.05f) {                                                        // :272-279
+                        const float q = 0.75f;
+                        if (in_range(w_event, 0.0f, 1.0f) < q) Tsh = 0.0f;
+                        else Tsh /= 1.0f - q;
                     }
-                    if (in_shadow) {
-                        Tsh *= att;
-                        if (Tsh < 0.05f) {                                                    // :272-279
-                            const float q = 0.75f;
-                            if (in_range(w_event, 0.0f, 1.0f) < q) Tsh = 0.0f;
-                            else Tsh /= 1.0f - q;
-                        }
-                        if (Tsh <= 0.0f) st = ST_SHADOW_DONE;                                 // :281
+                    if (Tsh <= 0.0f) st = ST_SHADOW_DONE;                                     // :281
+                } else {
+                    // collision type: null / absorption / scattering                         :98-100, :108
+                    bool is_null, is_absorb;
+                    if (EXACT) {
+                        const float mu_s = sigma * p.sigma_s;
+                        const float pA = M::div_(mu_a, p.sigma_maj);
+                        const float pS = M::div_(mu_s, p.sigma_maj);
+                        const float pn = 1 - pA - pS;
+                        const float pNull = (0 < pn) ? pn : 0;
+                        const float sample = in_range(w_event, 0.0f, 1.0f);
+                        is_null = sample < pNull;
+                        is_absorb = sample < pNull + pA;
                     } else {
-                        // collision type: null / absorption / scattering                     :98-100, :108
-                        bool is_null, is_absorb;
-                        if (EXACT) {
-                            const float mu_s = sigma * p.sigma_s;
-                            const float pA = M::div_(mu_a, p.sigma_maj);
-                            const float pS = M::div_(mu_s, p.sigma_maj);
-                            const float pn = 1 - pA - pS;
-                            const float pNull = (0 < pn) ? pn : 0;
-                            const float sample = in_range(w_event, 0.0f, 1.0f);
-                            is_null = sample < pNull;
-                            is_absorb = sample < pNull + pA;
-                        } else {
-                            // the same comparisons scaled by 2^24 (exact), against the raw 24-bit draw
-                            const float pA = sigma * fast_pa24, pS = sigma * fast_ps24;
-                            const float pNull = fmaxf(16777216.0f - pA - pS, 0.0f);
-                            const float sample = (float)(w_event >> 8);
-                            is_null = sample < pNull;
-                            is_absorb = sample < pNull + pA;
+                        // the same comparisons scaled by 2^24 (exact), against the raw 24-bit draw
+                        const float pA = sigma * fast_pa24, pS = sigma * fast_ps24;
+                        const float pNull = fmaxf(16777216.0f - pA - pS, 0.0f);
+                        const float sample = (float)(w_event >> 8);
+                        is_null = sample < pNull;
+                        is_absorb = sample < pNull + pA;
+                    }
+                    if (INTEG == INTEG_RATIO) T = T * att;
+                    if (INTEG == INTEG_RATIO && p.has_temperature) {                          // :110-122
+                        const TrackCold* c = opaque(p.cold);
+                        const float emission = grid_value_nocache(c->temperature, ray_at(eye, dir, t));
+                        n_lookups++;
+                        if (emission > 0.0f) {
+                            f3 e = scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), T * (sigma * p.sigma_a));
+                            e = scale3(e, emission);
+                            e = scale3(e, len);
+                            radiance = add3(radiance, e);
                         }
-                        if (INTEG == INTEG_RATIO) T = T * att;
-                        if (INTEG == INTEG_RATIO && p.has_temperature) {                      // :110-122
-                            const TrackCold* c = opaque(p.cold);
-                            const float emission = grid_value_nocache(c->temperature, ray_at(eye, dir, t));
-                            n_lookups++;
-                            if (emission > 0.0f) {
-                                f3 e = scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), T * (sigma * p.sigma_a));
-                                e = scale3(e, emission);
-                                e = scale3(e, len);
-                                radiance = add3(radiance, e);
-                            }
-                        }
-                        if (is_null) {
-                            // null collision
-                        } else if (is_absorb) {
-                            // absorption: the medium colour is added in the event phase      :127-131 (delta :101-113)
-                            if (INTEG == INTEG_DELTA && p.has_temperature) n_lookups++;       // accEmission.getValue, result unused (delta :103)
-                            scatter_len = sigma * p.sigma_a;
-                            st = ST_ABSORBED;
-                        } else {
-                            // scattering                                                    :133-191 (delta :115-158)
-                            depth_remaining--;                                                // :136 (the `< 0` test never fires)
-                            n_scatter++;
-                            if (INTEG == INTEG_DELTA || T > 0.0f) {                           // :141
-                                scatter_p = ray_at(eye, dir, t);                              // :162 (delta :130)
-                                scatter_len = len;
-                                st = INTEG == INTEG_DELTA ? ST_SHADOW_DONE : ST_SCATTER;
-                            }
+                    }
+                    if (is_null) {
+                        // null collision
+                    } else if (is_absorb) {
+                        // absorption: the medium colour is added in the event phase          :127-131 (delta :101-113)
+                        if (INTEG == INTEG_DELTA && p.has_temperature) n_lookups++;           // accEmission.getValue, result unused (delta :103)
+                        scatter_len = sigma * p.sigma_a;
+                        st = ST_ABSORBED;
+                    } else {
+                        // scattering                                                        :133-191 (delta :115-158)
+                        depth_remaining--;                                                    // :136 (the `< 0` test never fires)
+                        n_scatter++;
+                        if (INTEG == INTEG_DELTA || T > 0.0f) {                               // :141
+                            scatter_p = ray_at(eye, dir, t);                                  // :162 (delta :130)
+                            scatter_len = len;
+                            st = INTEG == INTEG_DELTA ? ST_SHADOW_DONE : ST_SCATTER;
                         }
                     }
                 }
             }
+            // empty-space steps: tFar += constant, no draw                                   :84-96 / :251-263 (delta :70-82)
+            if (empty) {
+                const bool  in_shadow = (INTEG == INTEG_RATIO) && shadow;
+                const float mult = in_shadow ? p.shadow_mult : p.light_mult;
+                const float tmin = in_shadow ? p.t_min * 5 : p.t_min;
+                const float len = in_shadow ? tmin * 100 : tmin * 10;                         // :252 / :85
+                uint32_t    krun = 1;
+                // a run must not span iterations that would play roulette (T < 0.05 on the camera walk)
+                const bool can_run = INTEG == INTEG_DELTA || in_shadow || !(T < 0.05f);
+                if (SKIP && cur_off != 0xffffffffu && can_run) {
+                    // an empty brick (majorant <= 0) is crossed in one run, else this voxel
+                    float t_safe = t_span;
+                    if (brick_major <= 0.0f && mult >= 0.0f) t_safe = brick_span();
+                    krun = empty_run(t, fminf(t_safe, t1), len);
+                } else {
+                    t += len;
+                }
+                n_lookups += krun;
+                rng_step += krun;
+                if (t > t1) st = in_shadow ? ST_SHADOW_DONE : ST_ESCAPED;                     // :91 / :258
+            }
+            // the voxel of the next trip's first iteration
+            if (st == ST_WALK) prefetch();
             // leave for the event phase once enough lanes wait for it, or none walks any more
             const int n_walk = __popcll(__ballot(st == ST_WALK));
             w_trips++; w_trip_lanes += (unsigned)n_walk;
