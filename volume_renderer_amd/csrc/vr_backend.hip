@@ -21,6 +21,8 @@
 
 using namespace vr;
 
+#define VR_SKIP_CAP 31   // largest empty-cube radius the skip grid records, in voxels
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -70,6 +72,55 @@ __global__ void __launch_bounds__(256) k_majorant(const float* __restrict__ bric
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if (lane == 0) majorant[wave] = m;
+}
+
+// ---- skip grid ----------------------------------------------------------------------------
+// For every empty voxel (value <= 0) the L-infinity distance d >= 1, in voxels and capped, to the
+// nearest voxel that is not empty or lies outside the bbox: every voxel of the cube of radius
+// d - 1 around it is then empty too, and a walk can take all its empty-space steps up to that
+// cube's boundary at once (empty_run).  The distance is separable: along k it is a 1-D distance,
+// along j then  d2(j) = min_j' max(|j - j'|, d1(j')),  along i the same over d2.
+__device__ __forceinline__ size_t brick_index(int i, int j, int k, int nby, int nbz)
+{
+    return ((((size_t)(i >> 3) * nby + (j >> 3)) * nbz + (k >> 3)) << 9) | (size_t)(((i & 7) << 6) | ((j & 7) << 3) | (k & 7));
+}
+__global__ void __launch_bounds__(256) k_skip_pass(const float* __restrict__ bricks, const uint8_t* __restrict__ in,
+                                                   uint8_t* __restrict__ out, int dx, int dy, int dz, int nbx, int nby, int nbz,
+                                                   int axis, int cap)
+{
+    const size_t total = (size_t)nbx * nby * nbz * 512;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t local = (uint32_t)(o & 511);
+        size_t         b = o >> 9;
+        const int bk = (int)(b % nbz); b /= nbz;
+        const int bj = (int)(b % nby);
+        const int bi = (int)(b / nby);
+        const int i = bi * 8 + (int)(local >> 6), j = bj * 8 + (int)((local >> 3) & 7), k = bk * 8 + (int)(local & 7);
+        if (i >= dx || j >= dy || k >= dz) { out[o] = 0; continue; }
+        const int c = axis == 2 ? k : (axis == 1 ? j : i), n = axis == 2 ? dz : (axis == 1 ? dy : dx);
+        auto at = [&](int cc) -> int {
+            if (cc < 0 || cc >= n) return 0;
+            const size_t oo = axis == 2 ? brick_index(i, j, cc, nby, nbz) : (axis == 1 ? brick_index(i, cc, k, nby, nbz) : brick_index(cc, j, k, nby, nbz));
+            return axis == 2 ? (bricks[oo] > 0.0f ? 0 : cap + 1) : (int)in[oo];
+        };
+        int best = at(c);
+        for (int d = 1; d < best; ++d) {
+            const int a = max(d, at(c - d)), e = max(d, at(c + d));
+            best = min(best, min(a, e));
+        }
+        out[o] = (uint8_t)min(best, cap + 1);
+    }
+}
+// skip[v] = value where it is > 0, else -(distance): sigma = multiplier * skip[v] keeps its sign for
+// multipliers >= 0, which is all the walks read of an empty voxel
+__global__ void __launch_bounds__(256) k_skip_make(const float* __restrict__ bricks, const uint8_t* __restrict__ dist,
+                                                   float* __restrict__ skip, size_t total)
+{
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const float v = bricks[o];
+        const int   d = dist[o];
+        skip[o] = (v > 0.0f || d == 0) ? v : -(float)d;     // d == 0: padding outside the bbox, never looked up
+    }
 }
 
 // Ken Perlin's reference permutation — the table of Utils/PerlinNoiseSampler.cpp:11-28 (data)
@@ -203,7 +254,7 @@ struct vr_backend {
 
     // density / temperature
     bool     has_density = false, has_temperature = false;
-    float*   d_bricks = nullptr;  float* d_major = nullptr;  GridDev grid{};
+    float*   d_bricks = nullptr;  float* d_skip = nullptr;  GridDev grid{};   // d_skip: see k_skip_pass
     float*   d_tbricks = nullptr; GridDev tgrid{};
     float    inv_mat[9]{}, vec[3]{};
     float    bmin[3]{}, bmax1[3]{};
@@ -304,21 +355,43 @@ int upload_grid(vr_backend* b, const vr_grid_desc* g, float*& d_bricks, GridDev&
     return VR_OK;
 }
 
-int build_majorant(vr_backend* b)
+// max value (nanovdb::getExtrema(grid, bbox).max(), SceneLoader.cpp:219) and the skip grid
+int build_derived(vr_backend* b)
 {
-    const uint32_t nbricks = (uint32_t)b->grid.nb[0] * b->grid.nb[1] * b->grid.nb[2];
-    if (b->d_major) { (void)hipFree(b->d_major); b->d_major = nullptr; }
-    HIP_TRY(b, hipMalloc((void**)&b->d_major, (size_t)nbricks * sizeof(float)));
-    k_majorant<<<(nbricks + 3) / 4, 256, 0, b->stream>>>(b->d_bricks, b->d_major, nbricks);
-    HIP_TRY(b, hipGetLastError());
+    const GridDev& g = b->grid;
+    const uint32_t nbricks = (uint32_t)g.nb[0] * g.nb[1] * g.nb[2];
+    const size_t   total = (size_t)nbricks * 512;
+    float* d_major = nullptr;
+    HIP_TRY(b, hipMalloc((void**)&d_major, (size_t)nbricks * sizeof(float)));
+    k_majorant<<<(nbricks + 3) / 4, 256, 0, b->stream>>>(b->d_bricks, d_major, nbricks);
+    hipError_t e = hipGetLastError();
     std::vector<float> h(nbricks);
-    HIP_TRY(b, hipMemcpyAsync(h.data(), b->d_major, (size_t)nbricks * sizeof(float), hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(b, hipStreamSynchronize(b->stream));
-    // nanovdb::getExtrema(grid, bbox).max() (SceneLoader.cpp:219): padding voxels hold the background,
-    // which getExtrema also sees for inactive voxels inside the bbox
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_major, (size_t)nbricks * sizeof(float), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d_major);
+    if (e != hipSuccess) return fail(b, VR_ERR_HIP, "majorant: %s", hipGetErrorString(e));
+    // padding voxels hold the background, which getExtrema also sees for inactive voxels inside the bbox
     float m = h[0];
     for (uint32_t i = 1; i < nbricks; ++i) if (h[i] > m) m = h[i];
     b->max_value = m;
+
+    if (b->d_skip) { (void)hipFree(b->d_skip); b->d_skip = nullptr; }
+    uint8_t *d_a = nullptr, *d_b = nullptr;
+    e = hipMalloc((void**)&b->d_skip, total * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_a, total);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_b, total);
+    if (e == hipSuccess) {
+        const int blocks = grid_blocks(total, 65536);
+        k_skip_pass<<<blocks, 256, 0, b->stream>>>(b->d_bricks, nullptr, d_a, g.dim[0], g.dim[1], g.dim[2], g.nb[0], g.nb[1], g.nb[2], 2, VR_SKIP_CAP);
+        k_skip_pass<<<blocks, 256, 0, b->stream>>>(b->d_bricks, d_a, d_b, g.dim[0], g.dim[1], g.dim[2], g.nb[0], g.nb[1], g.nb[2], 1, VR_SKIP_CAP);
+        k_skip_pass<<<blocks, 256, 0, b->stream>>>(b->d_bricks, d_b, d_a, g.dim[0], g.dim[1], g.dim[2], g.nb[0], g.nb[1], g.nb[2], 0, VR_SKIP_CAP);
+        k_skip_make<<<blocks, 256, 0, b->stream>>>(b->d_bricks, d_a, b->d_skip, total);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    if (e != hipSuccess) return fail(b, e == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP, "skip grid: %s", hipGetErrorString(e));
     return VR_OK;
 }
 
@@ -568,10 +641,13 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 const float typical = std::min(std::max(o->stepSizeMin, mean_free), o->stepSizeMax);
                 p.use_span = (typical < 0.25f && span_ok) ? 1 : 0;
             }
-            p.majorant = b->d_major;
             void (*kern)(const TrackParams);
             const bool ratio = integrator == VR_INTEGRATOR_RATIO_TRACKING;
-            switch (span_ok ? b->mode : (b->mode == VR_MODE_FAST ? -1 : VR_MODE_EXACT)) {
+            // empty-space runs read the skip grid, whose empty voxels only keep the sign of sigma for
+            // multipliers >= 0 (the shadow multiplier is only read by the ratio tracker)
+            const bool skip_ok = span_ok && o->lightRayDensityMultiplier >= 0.0f && (!ratio || o->shadowRayDensityMultiplier >= 0.0f);
+            if (skip_ok && b->mode != VR_MODE_EXACT) p.density.bricks = b->d_skip;
+            switch (skip_ok ? b->mode : (b->mode == VR_MODE_FAST ? -1 : VR_MODE_EXACT)) {
             case -1:                 kern = ratio ? vr_track_kernel<INTEG_RATIO, false, false> : vr_track_kernel<INTEG_DELTA, false, false>; break;
             case VR_MODE_EXACT:      kern = ratio ? vr_track_kernel<INTEG_RATIO, true, false> : vr_track_kernel<INTEG_DELTA, true, false>; break;
             case VR_MODE_EXACT_SKIP: kern = ratio ? vr_track_kernel<INTEG_RATIO, true, true> : vr_track_kernel<INTEG_DELTA, true, true>; break;
@@ -675,7 +751,7 @@ void vr_backend_destroy(vr_backend* b)
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    void* ptrs[] = { b->d_bricks, b->d_major, b->d_tbricks, b->d_nodes, b->d_tris, b->d_p2s, b->d_dissolve, b->d_samples,
+    void* ptrs[] = { b->d_bricks, b->d_skip, b->d_tbricks, b->d_nodes, b->d_tris, b->d_p2s, b->d_dissolve, b->d_samples,
                      b->d_rows, b->d_offsets, b->d_work, b->d_counters, b->d_maxbits, b->d_cold };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (Pass& p : b->passes) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -714,7 +790,7 @@ int vr_backend_set_density(vr_backend* b, const vr_grid_desc* density, const vr_
     rc = upload_grid(b, density, b->d_bricks, b->grid);
     if (rc) return rc;
     set_map(b, density->inv_mat, density->vec, density->bbox_min, density->bbox_max);
-    rc = build_majorant(b);
+    rc = build_derived(b);
     if (rc) return rc;
     if (density->max_value >= 0.0f) b->max_value = density->max_value;   // the caller's getExtrema result
     if (temperature) {
@@ -749,7 +825,7 @@ int vr_backend_generate_cloud(vr_backend* b, int n, float radius_voxels)
     b->grid.background = 0.0f;
     const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, zero[3] = { 0, 0, 0 };
     set_map(b, ident, zero, bmin, bmax);
-    rc = build_majorant(b);
+    rc = build_derived(b);
     if (rc) return rc;
     b->has_density = true;
     return VR_OK;

@@ -69,8 +69,7 @@ struct TrackCold {
 struct TrackParams {
     const TrackCold* cold;
     WorkDev   work;
-    GridDev   density;
-    const float* majorant;           // per-brick max of the density grid
+    GridDev   density;               // SKIP kernels: the skip grid (empty voxels hold -(empty-cube radius + 1))
     int32_t   has_temperature;
     int32_t   use_span;              // steps are much shorter than a voxel: remember the voxel's t-interval
     int32_t   round_max, round_events; // step-loop trips per round / waiting lanes that end a round early
@@ -175,7 +174,6 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
     float    cur_val = 0.0f;
     uint32_t cur_off = 0xffffffffu;     // its voxel offset (0xffffffff: outside the bbox)
     float    t_span = 0.0f;             // while t < t_span the walk is provably still inside that voxel
-    float    brick_major = 1.0f;        // majorant of that voxel's 8^3 brick (fetched with the voxel)
     unsigned long long n_lookups = 0;
     uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0;
     unsigned long long w_trips = 0, w_trip_lanes = 0, w_phases = 0;   // wave-uniform divergence counters
@@ -190,28 +188,24 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
         const int32_t i = (int32_t)fx - p.density.min[0], j = (int32_t)fy - p.density.min[1], k = (int32_t)fz - p.density.min[2];
         const bool in = (uint32_t)i < (uint32_t)p.density.dim[0] && (uint32_t)j < (uint32_t)p.density.dim[1] &&
                         (uint32_t)k < (uint32_t)p.density.dim[2];
-        float    n_val = p.density.background, n_span = t, n_major = brick_major;
+        float    n_val = p.density.background, n_span = t;
         uint32_t n_off = 0xffffffffu;
         if (in) {
             n_off = brick_offset(p.density, (uint32_t)i, (uint32_t)j, (uint32_t)k);
             n_val = cur_val;
             if (n_off != cur_off) n_val = p.density.bricks[n_off];
-            if (SKIP && (cur_off == 0xffffffffu || (n_off >> 9) != (cur_off >> 9))) n_major = p.majorant[n_off >> 9];
             if (p.use_span || SKIP)
                 // ray parameter at which the walk leaves the voxel shrunk by `slack` on every side (see empty_run)
                 n_span = fminf(fminf((fx + span_off.x) * inv.x, (fy + span_off.y) * inv.y), (fz + span_off.z) * inv.z);
         }
-        cur_val = n_val; cur_off = n_off; t_span = n_span; brick_major = n_major;
+        cur_val = n_val; cur_off = n_off; t_span = n_span;
     };
-    // same bound for the 8^3 brick around iRay(t); only needed when that brick is empty
-    auto brick_span = [&]() -> float {
+    // same bound for the cube of `radius` voxels around the voxel of iRay(t)
+    auto cube_span = [&](float radius) -> float {
         const f3 q = ray_at(eye, dir, t);
-        // brick origin: floor to a multiple of 8 relative to bbox.min (a multiple of 8 voxels from it)
-        const float ox = (float)p.density.min[0], oy = (float)p.density.min[1], oz = (float)p.density.min[2];
-        const float bx = ox + 8.0f * floorf((floorf(q.x) - ox) * 0.125f) + (dir.x > 0 ? 7.0f : 0.0f);
-        const float by = oy + 8.0f * floorf((floorf(q.y) - oy) * 0.125f) + (dir.y > 0 ? 7.0f : 0.0f);
-        const float bz = oz + 8.0f * floorf((floorf(q.z) - oz) * 0.125f) + (dir.z > 0 ? 7.0f : 0.0f);
-        return fminf(fminf((bx + span_off.x) * inv.x, (by + span_off.y) * inv.y), (bz + span_off.z) * inv.z);
+        const float cx = floorf(q.x) + copysignf(radius, dir.x), cy = floorf(q.y) + copysignf(radius, dir.y),
+                    cz = floorf(q.z) + copysignf(radius, dir.z);
+        return fminf(fminf((cx + span_off.x) * inv.x, (cy + span_off.y) * inv.y), (cz + span_off.z) * inv.z);
     };
     auto set_ray = [&](f3 e, f3 d, float a, float b) {
         eye = e; dir = d; t = a; t1 = b;
@@ -491,16 +485,15 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
             // empty-space steps: tFar += constant, no draw                                   :84-96 / :251-263 (delta :70-82)
             if (empty) {
                 const bool  in_shadow = (INTEG == INTEG_RATIO) && shadow;
-                const float mult = in_shadow ? p.shadow_mult : p.light_mult;
                 const float tmin = in_shadow ? p.t_min * 5 : p.t_min;
                 const float len = in_shadow ? tmin * 100 : tmin * 10;                         // :252 / :85
                 uint32_t    krun = 1;
                 // a run must not span iterations that would play roulette (T < 0.05 on the camera walk)
                 const bool can_run = INTEG == INTEG_DELTA || in_shadow || !(T < 0.05f);
                 if (SKIP && cur_off != 0xffffffffu && can_run) {
-                    // an empty brick (majorant <= 0) is crossed in one run, else this voxel
+                    // the skip grid holds -(r + 1) where every voxel of the cube of radius r is empty
                     float t_safe = t_span;
-                    if (brick_major <= 0.0f && mult >= 0.0f) t_safe = brick_span();
+                    if (cur_val < -1.5f) t_safe = cube_span(-1.0f - cur_val);
                     krun = empty_run(t, fminf(t_safe, t1), len);
                 } else {
                     t += len;
