@@ -367,9 +367,10 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
             const uint32_t block = rng_step >> 1;
             if (st == ST_WALK) philox4x32_10(rng_pixel, rng_sample, rng_tag, block, k0, k1, w0, w1, w2, w3);
             bool empty = false;     // this lane's current iteration is an empty-space step, still to be taken
+            bool parked = false;    // this lane has left its voxel and waits for the lookup at the end of the trip
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                if (st != ST_WALK || empty || (half && (rng_step >> 1) != block)) continue;
+                if (st != ST_WALK || empty || parked || (half && (rng_step >> 1) != block)) continue;
                 // (the second half only ever sees odd steps)
                 const bool     odd = half || (rng_step & 1u);
                 const uint32_t w_path = odd ? w2 : w0, w_event = odd ? w3 : w1;
@@ -407,9 +408,13 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                 t += len;                                                                     // :88 / :255
                 n_lookups += 1;
                 rng_step += 1;
-                // the second iteration's voxel, requested as early as its position is known (the
-                // voxel for the next trip is requested after the runs below)
-                if (half == 0 && t <= t1) prefetch();
+                // the second iteration's voxel.  With sub-voxel steps (use_span) few lanes need one,
+                // yet nearly every wave has such a lane: it sits out the second half instead and
+                // is served by the lookup at the end of the trip.
+                if (half == 0 && t <= t1) {
+                    if (p.use_span) parked = !(t < t_span);
+                    else prefetch();
+                }
                 if (t > t1) {                                                                 // :91 / :258
                     st = in_shadow ? ST_SHADOW_DONE : ST_ESCAPED;                             // shadow walk returns its transmission
                     continue;
