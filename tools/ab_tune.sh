@@ -1,0 +1,6 @@
+#!/bin/bash
+# A/B of tuning env settings at the full headline workload, same box, one process per point
+for cfg in "24 6" "24 12" "24 20" "48 12" "24 6"; do
+  set -- $cfg
+  VR_TUNE_ROUND_MAX=$1 VR_TUNE_ROUND_EVENTS=$2 timeout -k 10 120 python -u bench.py --steps 2 --warmup 1 --cpu-baseline off 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('round_max $1 events $2', round(d['value'],1), 'Msamples/s', round(d['ms_per_step'],1), 'ms lanes', round(d['divergence']['walking_lanes_per_trip'],1), d['divergence']['wave_trips'], d['divergence']['event_phases'])"
+done

@@ -125,8 +125,8 @@ enum {
     // events, served by the event phase (every state >= ST_SCATTER)
     ST_SCATTER = 3, ST_SHADOW_DONE = 4, ST_FINISHED = 5, ST_ESCAPED = 6, ST_ABSORBED = 7
 };
-#define VR_ROUND_MAX 24      // step-loop trips before the event phase runs regardless
-#define VR_ROUND_EVENTS 6    // ... or as soon as this many lanes wait for it
+#define VR_ROUND_MAX 48      // step-loop trips before the event phase runs regardless
+#define VR_ROUND_EVENTS 12   // ... or as soon as this many lanes wait for it
 
 // hide a pointer's provenance: loads through it stay ordinary vector loads inside the phase
 template <typename T>
