@@ -81,6 +81,45 @@ def test_tracking_exact_mode_is_bit_identical(backend, oracle, cloud64, integ, r
     assert st["step_limit_hits"] == 0
 
 
+def _holes_grid():
+    """Ragged dims, a positive background outside the bbox, holes of zeros and negative values:
+    everything that decides what the skip grid may call "empty".  (NaN voxels are out of contract:
+    the reference walks on with NaN transmission, the GPU path treats them as empty)"""
+    rng = np.random.default_rng(11)
+    n = (37, 50, 29)
+    x, y, z = np.meshgrid(*(np.arange(m, dtype=np.float32) for m in n), indexing="ij")
+    blob = np.sin(x * 0.31) * np.cos(y * 0.23) * np.sin(z * 0.41 + 1.0)
+    vox = np.where(blob > 0.15, blob, 0.0).astype(np.float32)          # ~1/3 dense, irregular holes
+    vox[rng.uniform(size=n) < 0.02] = -0.5                              # negative voxels are empty too (multiplier >= 0)
+    vox[12:30, 20:44, 8:22] = 0.0                                      # a large empty box inside
+    return Grid(vox, bbox_min=(-18, -25, -14), background=0.05, max_value=float(vox.max()))
+
+
+@pytest.mark.parametrize("integ", [RATIO, DELTA])
+@pytest.mark.parametrize("mults", [(1.0, 1.0), (0.0, 2.5), (-1.0, 1.0), (1.5, -2.0)], ids=["pos", "zero", "neg_light", "neg_shadow"])
+def test_skip_grid_runs_do_not_change_image_or_counts(backend, oracle, integ, mults):
+    """Empty-space runs over the skip grid (cubes of empty voxels) against the single-stepping
+    oracle.  Negative multipliers turn negative voxels into dense ones: the backend must then not
+    use the skip grid."""
+    g = _holes_grid()
+    o = scenes.options_cloud(integ, 64, 40, 36, 3, regime="shipped")
+    o.cameraPosition[2] = 60.0
+    o.lightRayDensityMultiplier, o.shadowRayDensityMultiplier = mults
+    o.stepSizeMax = 4.0
+    sc, _keep = ol.make_scene(density=g)
+    want, wst = oracle_image(oracle, sc, o, integ)
+    backend.set_density(g)
+    backend.set_seed(scenes.SEED)
+    for mode in (MODE_EXACT, MODE_EXACT_SKIP):
+        backend.set_mode(mode)
+        got = backend.render(o, integ)
+        st = backend.last_stats()
+        assert bitexact(got, want), f"mode {mode}: {np.count_nonzero(got.view(np.uint32) != want.view(np.uint32))} of {got.size} channels differ"
+        for k in ("path_samples", "density_lookups", "scatter_events", "shadow_rays"):
+            assert st[k] == wst[k], (mode, k)
+    assert wst["density_lookups"] > 20 * wst["path_samples"]           # the walks did cross the grid
+
+
 def test_tracking_exact_with_rotation_crop_and_temperature(backend, oracle, cloud64):
     rng = np.random.default_rng(5)
     temp = Grid((rng.uniform(0, 2, size=(40, 40, 40)) * (rng.uniform(size=(40, 40, 40)) < 0.5)).astype(np.float32),
