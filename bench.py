@@ -42,7 +42,12 @@ WORKLOADS = {
     "config3_textbook": ("deltaTracking", 512, 1920, 1080, 256, "textbook"),
     "config4_delta_4k_256spp_cloud1024": ("deltaTracking", 1024, 3840, 2160, 256, "textbook"),
     "small": ("ratioTracking", 128, 480, 270, 4, "shipped"),
+    # mesh-bounded homogeneous media (BASELINE configs 1 and 5): (integrator, mesh, width, height, spp, -)
+    "config1_marcher_cube_512_1spp": ("homogeneousRayMarcherNEE", "cube", 512, 512, 1, "mesh"),
+    "config5_marcher_sphere_4k": ("homogeneousRayMarcherImproved", "icosphere", 3840, 2160, 64, "mesh"),
+    "config5_marcher_nee_sphere_4k": ("homogeneousRayMarcherNEE", "icosphere", 3840, 2160, 64, "mesh"),
 }
+BVH_NODE_BYTES = 36            # one BvhNode per closest-hit query at the least (vr_kernels.h)
 
 
 def parse():
@@ -125,12 +130,18 @@ def main():
     if a.spp:
         spp = a.spp
     integ_id = INTEGRATORS[integ]
-    opts = scenes.options_cloud(integ, n, W, H, spp, regime=regime)
+    mesh_scene = regime == "mesh"
 
     be = Backend(local)
     be.set_mode(MODE_EXACT if a.mode == "exact" else MODE_FAST)
     be.set_seed(scenes.SEED)
-    be.generate_cloud(n, scenes.cloud_radius(n))     # density resident in HBM before timing
+    if mesh_scene:
+        opts = scenes.options_marcher(W, H, spp)
+        mesh = scenes.cube_mesh() if n == "cube" else scenes.icosphere_mesh()
+        be.set_mesh(mesh)                            # BVH resident in HBM before timing
+    else:
+        opts = scenes.options_cloud(integ, n, W, H, spp, regime=regime)
+        be.generate_cloud(n, scenes.cloud_radius(n))     # density resident in HBM before timing
 
     from volume_renderer_amd.scheduler import RowScheduler
     sched = RowScheduler(H, W, dev, rank=rank, world=world)
@@ -163,7 +174,7 @@ def main():
         stats = be.last_stats()
         kernel_ms += stats["kernel_ms"]
         launches += stats["kernel_launches"]
-        lookups += stats["density_lookups"]
+        lookups += stats["ray_queries"] if mesh_scene else stats["density_lookups"]
     fence()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -179,7 +190,7 @@ def main():
         value = samples_per_step * a.steps / dt / 1e6
         # dominant kernel = the tracking kernel; per-launch averages over every rank's launches
         avg_launch_s = kernel_ms_all / 1e3 / max(launches_all, 1.0)
-        bytes_per_launch = lookups_all * BYTES_PER_LOOKUP / max(launches_all, 1.0)
+        bytes_per_launch = lookups_all * (BVH_NODE_BYTES if mesh_scene else BYTES_PER_LOOKUP) / max(launches_all, 1.0)
         achieved = bytes_per_launch / max(avg_launch_s, 1e-12) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -201,7 +212,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": a.workload, "integrator": integ, "image": f"{W}x{H}", "spp": spp,
-                "grid": f"{n}^3 procedural cloud (Perlin fbm), bricked 8^3, replicated per GPU", "step_regime": regime,
+                "grid": (f"{n} mesh, threaded BVH" if mesh_scene else
+                         f"{n}^3 procedural cloud (Perlin fbm), bricked 8^3, replicated per GPU"), "step_regime": regime,
                 "kernel_mode": a.mode, "partition": f"rows r::{world} per rank, RCCL all_gather" if world > 1 else "single GPU",
                 "frame_mean_rgb": [float(x) for x in frame.mean(dim=(0, 1)).tolist()],
             },
@@ -215,11 +227,13 @@ def main():
                 "kernel": "vr_track_kernel" if integ_id >= 2 else "vr_march_kernel",
                 "kernel_ms_per_launch": avg_launch_s * 1e3, "launches": int(launches_all),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "note": "algorithmic bytes = 4 B x in-kernel lookup count; sub-voxel steps are served from a register, so "
-                        "frac measures lookup rate, not HBM traffic (see traffic)",
+                "note": ("algorithmic bytes = 36 B (one BVH node) x closest-hit queries: a lower bound, the BVH is L2-resident"
+                         if mesh_scene else
+                         "algorithmic bytes = 4 B x in-kernel lookup count; sub-voxel steps are served from a register, so "
+                         "frac measures lookup rate, not HBM traffic (see traffic)"),
             },
         }
-        want_cpu = a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and world == 1)
+        want_cpu = (a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and world == 1)) and not mesh_scene
         if want_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(integ_id, n, opts, a.cpu_seconds)
