@@ -657,6 +657,11 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             rc = launch_cap(b, kern, p, per_cu);
             if (rc) return rc;
             const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_cu * b->num_cu, (work.nitems + 255ull) / 256));
+            // a wave's chunk: large enough that the counter's atomics do not serialise the launch, small
+            // enough that the last chunks balance and that all waves stay on the same few image rows
+            // (measured: 64-128 best on every workload, 2048 costs 8 % in L2 locality)
+            const uint64_t fair = work.nitems / ((uint64_t)blocks * 4 * 8);
+            p.work.chunk = (uint32_t)std::min<uint64_t>((uint64_t)tune_int("VR_TUNE_CHUNK", 128), std::max<uint64_t>(64, fair & ~63ull));
             HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
             HIP_TRY(b, hipGetLastError());

@@ -45,6 +45,7 @@ struct CameraDev {
 
 struct WorkDev {
     uint32_t           nitems;      // s_count * nrows * width
+    uint32_t           chunk;       // items a wave takes from the counter at a time (tracking kernel)
     uint32_t*          counter;     // next item
     float*             samples;     // [s_count][nrows][width][3]
     Counters*          counters;
@@ -177,6 +178,8 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
     unsigned long long n_lookups = 0;
     uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0;
     unsigned long long w_trips = 0, w_trip_lanes = 0, w_phases = 0;   // wave-uniform divergence counters
+    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's own range of work items
+    bool     chunk_dry = false;               // the global counter has run past the last item
 
     // value at iRay(t) for the coming trip (nearest voxel by floor, background outside).  Results
     // are collected in locals and assigned once at the end: every state variable is then written on
@@ -302,20 +305,32 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
             store_sample(p.work.samples, item, radiance);
             st = ST_NEED;
         }
-        // (4) refill: idle lanes take the next items
+        // (4) refill: idle lanes take the next items of the wave's chunk; the wave takes a new chunk
+        // from the global counter when its own is used up.  (One atomic per refill on a single
+        // address serialises at ~11 ns each in L2 and was the bound of every short-path workload.)
         for (;;) {
             const bool               want = st == ST_NEED;
             const unsigned long long need = __ballot(want);
             if (need == 0ull) break;
-            const int leader = __ffsll((long long)need) - 1;
-            uint32_t  base = 0;
-            if (lane == leader) base = atomicAdd(p.work.counter, (uint32_t)__popcll(need));
-            base = __shfl(base, leader);
-            if (want) {
-                const uint32_t mine = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (mine >= p.work.nitems) {
-                    st = ST_EXHAUSTED;
-                } else {
+            if (chunk_next == chunk_end) {
+                if (chunk_dry) {
+                    if (want) st = ST_EXHAUSTED;
+                    break;
+                }
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(p.work.counter, p.work.chunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                chunk_next = base < p.work.nitems ? base : p.work.nitems;
+                chunk_end = base + p.work.chunk < p.work.nitems ? base + p.work.chunk : p.work.nitems;
+                if (chunk_next == chunk_end) { chunk_dry = true; continue; }
+            }
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            const uint32_t avail = chunk_end - chunk_next, asked = (uint32_t)__popcll(need);
+            const uint32_t first = chunk_next;
+            chunk_next += asked < avail ? asked : avail;
+            if (want && rank < avail) {
+                const uint32_t mine = first + rank;
+                {
                     const TrackCold* c = opaque(p.cold);
                     item = mine;
                     const uint32_t x = mine % c->cam.width;
