@@ -120,6 +120,29 @@ def test_skip_grid_runs_do_not_change_image_or_counts(backend, oracle, integ, mu
     assert wst["density_lookups"] > 20 * wst["path_samples"]           # the walks did cross the grid
 
 
+@pytest.mark.parametrize("integ", [RATIO, DELTA])
+@pytest.mark.parametrize("regime", ["shipped", "textbook"])
+def test_importance_sampling_output_mode(backend, oracle, cloud64, integ, regime):
+    """useImportanceSampling (BaseIntegrator.cpp:66-82): every sample is divided by max(0.1, path pdf),
+    the pdf picking up mu_t * attenuation per collision and the phase function per scatter."""
+    o = scenes.options_cloud(integ, 64, 40, 32, 4, regime=regime, useImportanceSampling=1)
+    sc, _ = ol.make_scene(density=cloud64)
+    want, wst = oracle_image(oracle, sc, o, integ)
+    plain, _ = oracle_image(oracle, sc, copy_options(o, useImportanceSampling=0), integ)
+    assert not bitexact(want, plain)                                    # the mode does change the image
+    backend.set_density(cloud64)
+    backend.set_seed(scenes.SEED)
+    for mode in (MODE_EXACT, MODE_EXACT_SKIP):
+        backend.set_mode(mode)
+        got = backend.render(o, integ)
+        assert bitexact(got, want), f"mode {mode}: {np.count_nonzero(got.view(np.uint32) != want.view(np.uint32))} channels differ"
+        assert backend.last_stats()["density_lookups"] == wst["density_lookups"]
+    backend.set_mode(MODE_FAST)
+    fast = backend.render(o, integ)
+    close = np.isclose(fast, want, rtol=1e-3, atol=1e-6).all(axis=2).mean()
+    assert close > 0.97, close
+
+
 def test_tracking_exact_with_rotation_crop_and_temperature(backend, oracle, cloud64):
     rng = np.random.default_rng(5)
     temp = Grid((rng.uniform(0, 2, size=(40, 40, 40)) * (rng.uniform(size=(40, 40, 40)) < 0.5)).astype(np.float32),

@@ -528,7 +528,6 @@ int validate(vr_backend* b, const vr_options_pod* o, int integrator)
     if (o->width + o->widthStartOffset > 65536u || o->height + o->heightStartOffset > 65536u)
         return fail(b, VR_ERR_INVALID_ARG, "image coordinates must stay below 65536 (Philox pixel key)");
     if (o->maxDepth > 255) return fail(b, VR_ERR_INVALID_ARG, "maxDepth is a uint8_t in the reference (Types.h:101)");
-    if (o->useImportanceSampling) return fail(b, VR_ERR_UNSUPPORTED, "importanceSampling is not implemented on the GPU path yet");
     if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
         if (!b->has_density) return fail(b, VR_ERR_NO_DENSITY, "tracking integrators need a density grid (SceneLoader.cpp:212-213)");
         // every step must advance t in float, or the reference's loops never end
@@ -629,6 +628,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             TrackParams p{};
             p.cold = b->d_cold; p.work = work;
             p.density = b->grid; p.has_temperature = b->has_temperature ? 1 : 0;
+            p.importance = o->useImportanceSampling ? 1 : 0;
             p.sigma_a = o->sigma_a; p.sigma_s = o->sigma_s;
             p.sigma_maj = b->max_value * (o->sigma_a + o->sigma_s);          // IntegratorRatioTracking.cpp:42-45
             p.t_min = o->stepSizeMin; p.t_max = o->stepSizeMax; p.step_mult = o->stepSizeMultiplier;

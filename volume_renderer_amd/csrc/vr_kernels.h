@@ -72,6 +72,7 @@ struct TrackParams {
     WorkDev   work;
     GridDev   density;               // SKIP kernels: the skip grid (empty voxels hold -(empty-cube radius + 1))
     int32_t   has_temperature;
+    int32_t   importance;            // Options::useImportanceSampling: track the path pdf, divide the sample by max(0.1, pdf)
     int32_t   use_span;              // steps are much shorter than a voxel: remember the voxel's t-interval
     int32_t   round_max, round_events; // step-loop trips per round / waiting lanes that end a round early
     float     sigma_a, sigma_s, sigma_maj;
@@ -166,6 +167,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
     f3       wdir = mk3(0, 0, 1);       // data->rayDirection
     f3       radiance = mk3(0, 0, 0);   // data->radiance / result
     float    T = 1.0f, Tsh = 1.0f;      // data->transmission, shadow-walk transmission
+    float    pdf = 1.0f;                // data->rayPDF (only read with useImportanceSampling)
     int      depth_remaining = 0;
     f3       scatter_p = mk3(0, 0, 0);  // iRay(tFar) of the pending scatter event
     float    scatter_len = 0;           // its pathLength (ST_ABSORBED: mu_a of the absorbing step)
@@ -282,6 +284,20 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                 const float xi1 = in_range(h0, 0.0f, 0.9999f);
                 const float xi2 = in_range(h1, 0.0f, 0.9999f);
                 const f3 scattered = hg_sample<EXACT>(c->g, wdir, xi1, xi2);              // :156-159
+                if (p.importance) {
+                    // path pdf *= phase function of the sampled direction                 :169-176 (delta :137-144)
+                    float cos_pdf;
+                    if (INTEG == INTEG_RATIO) {
+                        cos_pdf = dot3(scattered, wdir);
+                    } else {
+                        // the delta tracker takes the angle to the normalised PRIMARY direction (:22, :139)
+                        const uint32_t x = item % c->cam.width, q = item / c->cam.width;
+                        const uint32_t r = q % c->cam.nrows, s = c->cam.s_first + q / c->cam.nrows;
+                        const f3 primary = primary_direction(c->cam, c->cam.x0 + x, c->cam.y0 + c->cam.row_first + r * c->cam.row_stride, s);
+                        cos_pdf = dot3(normalize3(primary), wdir);
+                    }
+                    pdf *= hg_phase(c->g, cos_pdf);
+                }
                 wdir = scattered;                                                         // :178
                 rng_tag += 1; rng_step = 0;
                 shadow = false;
@@ -302,6 +318,11 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
         }
         // (3) finished paths store their sample
         if (st == ST_FINISHED) {
+            if (p.importance) {
+                // color += rayResults[i] / std::max(0.1f, rayPDFs[i])                     BaseIntegrator.cpp:78
+                const float den = (0.1f < pdf) ? pdf : 0.1f;
+                radiance = mk3(radiance.x / den, radiance.y / den, radiance.z / den);
+            }
             store_sample(p.work.samples, item, radiance);
             st = ST_NEED;
         }
@@ -361,6 +382,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                         T = 1.0f;
                         depth_remaining = (int)c->max_depth;
                         rng_pixel = (cj << 16) | ci; rng_sample = s; rng_tag = 0; rng_step = 0;
+                        pdf = 1.0f;                                                       // :14
                         set_ray(ieye, ndir, c0, c1);
                     }
                 }
@@ -439,9 +461,12 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                 if (EXACT) {
                     mu_a = sigma * p.sigma_a;
                     const float mu_t = mu_a + sigma * p.sigma_s;
-                    if (INTEG == INTEG_RATIO) att = M::exp_(-(len)*mu_t);
+                    if (INTEG == INTEG_RATIO || p.importance) att = M::exp_(-(len)*mu_t);
+                    // rayPDF *= mu_t * sampleAttenuation (a double there)                 :106 (delta :91)
+                    if (p.importance && !in_shadow) pdf = (float)((double)pdf * ((double)mu_t * (double)att));
                 } else {
-                    if (INTEG == INTEG_RATIO) att = __builtin_amdgcn_exp2f(len * (sigma * fast_sig_t2));
+                    if (INTEG == INTEG_RATIO || p.importance) att = __builtin_amdgcn_exp2f(len * (sigma * fast_sig_t2));
+                    if (p.importance && !in_shadow) pdf *= (sigma * fast_sig_t) * att;
                 }
                 if (in_shadow) {
                     Tsh *= att;
