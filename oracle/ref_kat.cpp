@@ -20,8 +20,11 @@
 #include "PerlinNoiseSampler.h"
 #include "MultithreadingHelper.h"
 #include "nanovdb/util/GridBuilder.h"
+#include "tinyobjloader/tiny_obj_loader.h"   // declarations; the implementation TU is compiled in place (Makefile)
 
 #include <cstring>
+
+#include "../volume_renderer_amd/host/NanoVdbBridge.hpp"   // OURS, instantiated on the reference's types
 
 float noise(float x, float y, float z); // defined (non-static) in Utils/PerlinNoiseSampler.cpp:46
 
@@ -167,5 +170,40 @@ void refk_ray_at(const float* eye, const float* dir, float t, float* out)
     out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
 }
 void refk_grid_destroy(void* h) { delete static_cast<RefGrid*>(h); }
+
+/* ---- our reference-side bridge (volume_renderer_amd/host/NanoVdbBridge.hpp) on the reference's types ---- */
+/* describeGrid on the grid above; voxels may be NULL to query the size first */
+long long refk_bridge_grid(void* h, int* bmin, int* bmax, float* inv_mat9, float* vec3, float* background_max2,
+                           float* voxels, long long capacity)
+{
+    auto* g = static_cast<RefGrid*>(h);
+    vr_host::DenseGrid dg;
+    vr_host::describeGrid(*g->grid, g->bbox, g->extrema.max(), dg);
+    for (int i = 0; i < 3; ++i) { bmin[i] = dg.desc.bbox_min[i]; bmax[i] = dg.desc.bbox_max[i]; vec3[i] = dg.desc.vec[i]; }
+    for (int i = 0; i < 9; ++i) inv_mat9[i] = dg.desc.inv_mat[i];
+    background_max2[0] = dg.desc.background; background_max2[1] = dg.desc.max_value;
+    const long long n = (long long)dg.voxels.size();
+    if (voxels && capacity >= n) memcpy(voxels, dg.voxels.data(), (size_t)n * sizeof(float));
+    return n;
+}
+/* tinyobj::LoadObj as SceneLoader.cpp:79 calls it, then describeMesh; counts[3] = nverts, ntris, nshapes;
+ * arrays may be NULL to query the counts first.  Returns 0 on success. */
+int refk_bridge_obj(const char* obj_path, const char* base_dir, unsigned* counts, float* verts, unsigned* tri_idx,
+                    unsigned* prim_to_shape, float* dissolve)
+{
+    tinyobj::attrib_t attrib;
+    std::vector<tinyobj::shape_t> shapes;
+    std::vector<tinyobj::material_t> materials;
+    std::string warn, err;
+    if (!tinyobj::LoadObj(&attrib, &shapes, &materials, &warn, &err, obj_path, base_dir)) return 1;
+    vr_host::TriangleSoup soup;
+    vr_host::describeMesh(attrib, shapes, materials, soup);
+    counts[0] = soup.desc.nverts; counts[1] = soup.desc.ntris; counts[2] = soup.desc.nshapes;
+    if (verts) memcpy(verts, soup.verts.data(), soup.verts.size() * sizeof(float));
+    if (tri_idx) memcpy(tri_idx, soup.tri_idx.data(), soup.tri_idx.size() * sizeof(unsigned));
+    if (prim_to_shape) memcpy(prim_to_shape, soup.prim_to_shape.data(), soup.prim_to_shape.size() * sizeof(unsigned));
+    if (dissolve) memcpy(dissolve, soup.shape_dissolve.data(), soup.shape_dissolve.size() * sizeof(float));
+    return 0;
+}
 
 } // extern "C"
