@@ -188,6 +188,46 @@ def test_render_rows_and_row_sets_tile_the_same_image(backend, oracle, cloud64):
     assert bitexact(full, out)
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 1, 16), (65, 2, 4), (129, 5, 1), (7, 67, 3)])
+def test_ragged_and_tiny_frames(backend, oracle, cloud64, shape):
+    """Frames smaller than a wave, widths that are not multiples of 64, a single pixel, spp that is not a
+    power of four (the reference's quadrant recursion then gives offset 0 for spp < 4): every item count
+    the work queue can see, including fewer items than one chunk."""
+    w, h, spp = shape
+    backend.set_density(cloud64)
+    backend.set_seed(scenes.SEED)
+    sc, _ = ol.make_scene(density=cloud64)
+    for integ in (RATIO, DELTA):
+        o = scenes.options_cloud(integ, 64, w, h, spp, regime="textbook", widthReference=160, heightReference=120,
+                                 widthStartOffset=40, heightStartOffset=50)
+        want, wst = oracle_image(oracle, sc, o, integ)
+        for mode in (MODE_EXACT, MODE_EXACT_SKIP):
+            backend.set_mode(mode)
+            got = backend.render(o, integ)
+            assert got.shape == (h, w, 3) and bitexact(got, want), (integ, mode)
+            assert backend.last_stats()["path_samples"] == w * h * spp == wst["path_samples"]
+
+
+def test_empty_row_set_and_mesh_frames(backend, oracle, cloud64):
+    """row_count == 0 is a no-op; the marchers take the same ragged shapes."""
+    import torch
+    backend.set_density(cloud64)
+    o = scenes.options_cloud(RATIO, 64, 16, 8, 1)
+    dev = torch.full((1, 16, 3), -7.0, dtype=torch.float32, device="cuda:0")
+    backend.render_row_set_device(o, RATIO, 0, 1, 0, dev.data_ptr())
+    backend.synchronize()
+    assert float(dev.min()) == -7.0 == float(dev.max())
+    mesh = scenes.icosphere_mesh()
+    backend.set_mesh(mesh)
+    backend.set_mode(MODE_EXACT)
+    sc, _ = ol.make_scene(mesh=mesh)
+    for w, h, spp in ((1, 1, 1), (67, 3, 4), (5, 130, 1)):
+        om = scenes.options_marcher(w, h, spp, widthReference=200, heightReference=200, widthStartOffset=66, heightStartOffset=35)
+        for integ in (NEE, IMPROVED):
+            want, _ = oracle_image(oracle, sc, om, integ)
+            assert bitexact(backend.render(om, integ), want), (w, h, spp, integ)
+
+
 @pytest.mark.parametrize("integ", [RATIO, DELTA])
 def test_tracking_fast_mode_tracks_the_oracle(backend, oracle, cloud64, integ):
     o = scenes.options_cloud(integ, 64, 64, 64, 16, regime="shipped")
