@@ -42,6 +42,8 @@ WORKLOADS = {
     "config3_textbook": ("deltaTracking", 512, 1920, 1080, 256, "textbook"),
     "config4_delta_4k_256spp_cloud1024": ("deltaTracking", 1024, 3840, 2160, 256, "textbook"),
     "small": ("ratioTracking", 128, 480, 270, 4, "shipped"),
+    # fixed-step grid marcher on the same cloud: one lookup per half-voxel step + light marches
+    "gridmarch_simple_1080p_cloud512": ("nanoVDBSimple", 512, 1920, 1080, 4, "shipped"),
     # mesh-bounded homogeneous media (BASELINE configs 1 and 5): (integrator, mesh, width, height, spp, -)
     "config1_marcher_cube_512_1spp": ("homogeneousRayMarcherNEE", "cube", 512, 512, 1, "mesh"),
     "config5_marcher_sphere_4k": ("homogeneousRayMarcherImproved", "icosphere", 3840, 2160, 64, "mesh"),
@@ -224,7 +226,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S, "traffic": traffic,
-                "kernel": "vr_track_kernel" if integ_id >= 2 else "vr_march_kernel",
+                "kernel": {0: "vr_march_kernel", 1: "vr_march_kernel", 4: "vr_gridmarch_kernel", 5: "vr_gridmarch_kernel"}.get(integ_id, "vr_track_kernel"),
                 "kernel_ms_per_launch": avg_launch_s * 1e3, "launches": int(launches_all),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": ("algorithmic bytes = 36 B (one BVH node) x closest-hit queries: a lower bound, the BVH is L2-resident"

@@ -80,7 +80,7 @@ int vr_backend_set_sample_buffer_bytes(vr_backend* b, uint64_t bytes);
 /* ---- the hot path -----------------------------------------------------------------------
  * vr_backend_render_rows replaces BaseIntegrator::renderPartial(Vec3f* orig, Vec3f* pix,
  * ThreadInfo*, const Options&, SceneInfo*) (integrators/BaseIntegrator.h:67, .cpp:287-325)
- * including the virtual castRay it calls (BaseIntegrator.h:65) for the four integrators of
+ * including the virtual castRay it calls (BaseIntegrator.h:65) for the integrators of
  * vr_integrator_id: absolute rows [from_row, to_row) (ThreadInfo::fromHeight/toHeight, i.e.
  * heightStartOffset already added), all columns [widthStartOffset, widthStartOffset+width);
  * writes width*(to_row-from_row) RGB float triples, row-major, first row first, into

@@ -22,7 +22,9 @@ typedef enum vr_integrator_id {
     VR_INTEGRATOR_HOMOGENEOUS_RAY_MARCHER_IMPROVED = 1, /* "homogeneousRayMarcherImproved" */
     VR_INTEGRATOR_RATIO_TRACKING                   = 2, /* "ratioTracking"                 */
     VR_INTEGRATOR_DELTA_TRACKING                   = 3, /* "deltaTracking"                 */
-    VR_INTEGRATOR_COUNT                            = 4
+    VR_INTEGRATOR_NANOVDB_SIMPLE                   = 4, /* "nanoVDBSimple"                 */
+    VR_INTEGRATOR_NANOVDB_EMISSION                 = 5, /* "nanoVDBEmission"               */
+    VR_INTEGRATOR_COUNT                            = 6
 } vr_integrator_id;
 
 /* POD mirror of `struct Options` (Utils/Types.h:85-122) without the strings/vectors.
@@ -69,6 +71,9 @@ typedef struct vr_options_pod {
  *          pads max by one voxel (nanovdb/util/Ray.h:401).
  * inv_mat, vec : world->index map, index = inv_mat * (world - vec)
  *          (nanovdb/NanoVDB.h:2262-2270), row-major 3x3.
+ * mat    : index->world map, world = mat * index + vec (Map::applyMapF, NanoVDB.h:2249): the
+ *          Map's own mMatF, not a numerical inverse.  Only the fixed-step grid marchers
+ *          (nanoVDBSimple / nanoVDBEmission) read it.
  * background : value returned outside the bbox (NanoVDB.h:3350).
  * max_value  : what nanovdb::getExtrema(...).max() returned (SceneLoader.cpp:219,223);
  *          pass a negative number to have it computed from the voxels. */
@@ -78,6 +83,7 @@ typedef struct vr_grid_desc {
     int32_t      bbox_max[3];
     float        inv_mat[9];
     float        vec[3];
+    float        mat[9];
     float        background;
     float        max_value;
 } vr_grid_desc;

@@ -131,6 +131,20 @@ void refk_grid_info(void* h, int* bmin, int* bmax, float* minmax, float* inv_mat
     for (int i = 0; i < 3; ++i) vec3[i] = m.mVecF[i];
     *background = g->grid->tree().background();
 }
+void refk_grid_mat(void* h, float* mat9)
+{
+    const nanovdb::Map& m = static_cast<RefGrid*>(h)->grid->map();
+    for (int i = 0; i < 9; ++i) mat9[i] = m.mMatF[i];
+}
+/* indexToWorldF as IntegratorNanoVDBSimple.cpp:41 calls it */
+void refk_index_to_world(void* h, const float* p, int n, float* out)
+{
+    auto* g = static_cast<RefGrid*>(h);
+    for (int i = 0; i < n; ++i) {
+        auto w = g->grid->indexToWorldF(nanovdb::Vec3<float>(p[3 * i], p[3 * i + 1], p[3 * i + 2]));
+        out[3 * i] = w[0]; out[3 * i + 1] = w[1]; out[3 * i + 2] = w[2];
+    }
+}
 float refk_grid_value(void* h, const float* p)
 {
     auto* g = static_cast<RefGrid*>(h);
@@ -174,13 +188,13 @@ void refk_grid_destroy(void* h) { delete static_cast<RefGrid*>(h); }
 /* ---- our reference-side bridge (volume_renderer_amd/host/NanoVdbBridge.hpp) on the reference's types ---- */
 /* describeGrid on the grid above; voxels may be NULL to query the size first */
 long long refk_bridge_grid(void* h, int* bmin, int* bmax, float* inv_mat9, float* vec3, float* background_max2,
-                           float* voxels, long long capacity)
+                           float* voxels, long long capacity, float* mat9)
 {
     auto* g = static_cast<RefGrid*>(h);
     vr_host::DenseGrid dg;
     vr_host::describeGrid(*g->grid, g->bbox, g->extrema.max(), dg);
     for (int i = 0; i < 3; ++i) { bmin[i] = dg.desc.bbox_min[i]; bmax[i] = dg.desc.bbox_max[i]; vec3[i] = dg.desc.vec[i]; }
-    for (int i = 0; i < 9; ++i) inv_mat9[i] = dg.desc.inv_mat[i];
+    for (int i = 0; i < 9; ++i) { inv_mat9[i] = dg.desc.inv_mat[i]; mat9[i] = dg.desc.mat[i]; }
     background_max2[0] = dg.desc.background; background_max2[1] = dg.desc.max_value;
     const long long n = (long long)dg.voxels.size();
     if (voxels && capacity >= n) memcpy(voxels, dg.voxels.data(), (size_t)n * sizeof(float));

@@ -475,6 +475,21 @@ static inline v3 mat_mult(const float* m, v3 p)
                    fmaf(p.x, m[3], fmaf(p.y, m[4], p.z * m[5])),
                    fmaf(p.x, m[6], fmaf(p.y, m[7], p.z * m[8])));
 }
+/* REF NanoVDB.h:1547-1553 matMult(mat, vec, xyz) = Map::applyMapF (:2249) = Grid::indexToWorldF (:2641) */
+static inline v3 index_to_world(const vr_grid_desc* g, v3 p)
+{
+    const float* m = g->mat;
+    return v3_make(fmaf(p.x, m[0], fmaf(p.y, m[1], fmaf(p.z, m[2], g->vec[0]))),
+                   fmaf(p.x, m[3], fmaf(p.y, m[4], fmaf(p.z, m[5], g->vec[1]))),
+                   fmaf(p.x, m[6], fmaf(p.y, m[7], fmaf(p.z, m[8], g->vec[2]))));
+}
+void vro_index_to_world(const vr_grid_desc* g, const float* p, int n, float* out)
+{
+    for (int i = 0; i < n; ++i) {
+        v3 w = index_to_world(g, v3_make(p[3 * i], p[3 * i + 1], p[3 * i + 2]));
+        out[3 * i] = w.x; out[3 * i + 1] = w.y; out[3 * i + 2] = w.z;
+    }
+}
 /* REF Ray.h:257-267 with NanoVDB.h:2262-2270 (applyInverseMapF / applyInverseJacobianF) */
 static inline iray ray_world_to_index(const vr_grid_desc* g, v3 weye, v3 wdir)
 {
@@ -1150,6 +1165,86 @@ static v3 cast_ray_marcher(path_ctx* d, int improved)
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* fixed-step marchers through the voxel grid                                            */
+/* (REF integrators/IntegratorNanoVDBSimple.cpp:10-95, IntegratorNanoVDBEmission.cpp:10-110; */
+/*  the two differ in the density scale and the emission term)                           */
+/* ------------------------------------------------------------------------------------ */
+static v3 cast_ray_grid_marcher(path_ctx* d, int emission_variant)
+{
+    const vr_options_pod* o = d->o;
+    const vr_grid_desc* grid = d->sc->density;
+    const vr_grid_desc* tgrid = d->sc->temperature;
+    v3 rayDirection = u_normalize(d->rayDirection);                         /* Simple :12 */
+    iray iRay = ray_world_to_index(grid, d->rayOrigin, d->rayDirection);    /* :15-20 */
+    if (!ray_clip(&iRay, grid)) return opt3(o->backgroundColor);           /* :22-24 */
+    float density = emission_variant ? 64.0f : 0.5f;                        /* Simple :25, Emission :35 */
+    float lightRayDensity = density * 0.5f;                                 /* :26 */
+    const float step_size = 0.5f;                                           /* :28 */
+    float transmittance = 1.0f;                                             /* :30 */
+    v3 result = v3_make(0, 0, 0);                                           /* :32 */
+    v3 light = opt3(o->lightPosition);
+    uint32_t n = 0;                                                         /* march step index (Philox counter) */
+
+    for (float t = iRay.t0; t < iRay.t1; t += step_size, ++n) {             /* :34 */
+        v3 ip = ray_at(&iRay, t);
+        float sigma = grid_value(grid, ip) * density;                       /* :36 */
+        d->st->density_lookups++;
+        float emissionValue = 0.0f;
+        v3 emission = v3_make(0, 0, 0);
+        if (emission_variant) {                                             /* Emission :47-48 */
+            emissionValue = grid_value(tgrid, ip) * 4.0f;
+            d->st->density_lookups++;
+            emission = v3_scale(opt3(o->emissionColor), emissionValue);
+        }
+        float sampleAttenuation = m_expf(-step_size * sigma);               /* :38 */
+        transmittance *= sampleAttenuation;                                 /* :40 */
+        v3 world = index_to_world(grid, ip);                                /* :42 */
+        d->rayDirection = light;                                            /* :44 */
+        d->rayOrigin = world;                                               /* :45 */
+
+        if (sigma > 0 || (emission_variant && emissionValue > 0)) {         /* Simple :47, Emission :61 */
+            /* castLightRay (:97-128): the light ray in index space, clipped to the bbox */
+            iray lRay = ray_world_to_index(grid, d->rayOrigin, d->rayDirection);
+            d->st->shadow_rays++;
+            if (ray_clip(&lRay, grid)) {                                    /* :49 */
+                float tau = 0;
+                float light_step_size = step_size * 20.0f;                  /* :52 */
+                float num_steps_light = ceilf(lRay.t1 / light_step_size);   /* :53 (t1, not t1 - t0) */
+                for (size_t nl = 0; (float)nl < num_steps_light; ++nl) {    /* :55 */
+                    float tLight = (float)(light_step_size * (nl + 0.5));   /* :56 (double product) */
+                    tau += grid_value(grid, ray_at(&lRay, lRay.t0 + tLight)) * lightRayDensity; /* :57 */
+                    d->st->density_lookups++;
+                }
+                float cos_theta = u_dot(rayDirection, light);               /* :60 */
+                float light_attenuation = m_expf(-tau * light_step_size * sigma); /* :61 */
+                v3 c = v3_scale(opt3(o->lightColor), light_attenuation);    /* :63-69, left to right */
+                c = v3_scale(c, sigma);
+                c = v3_scale(c, hg_phase(o->heyneyGreensteinG, cos_theta));
+                c = v3_scale(c, transmittance);
+                c = v3_scale(c, step_size);
+                result = v3_add(result, c);
+            } else {                                                        /* :73-78 */
+                v3 c = v3_scale(opt3(o->lightColor), sigma);
+                c = v3_scale(c, transmittance);
+                c = v3_scale(c, step_size);
+                result = v3_add(result, c);
+            }
+            if (emission_variant)                                           /* Emission :90 */
+                result = v3_add(result, v3_scale(v3_scale(emission, transmittance), step_size));
+            int dd = 2;                                                     /* :81-89 */
+            if (transmittance < 1e-3) {
+                float u;
+                if (d->rng->mode == VRO_RNG_REFERENCE) u = vro_reference_get_float(d->rng->mt, 0, 1);
+                else u = (unit24(rng_block(d->rng, 0u, n)[1]) * (1.0f - 0.0f)) + 0.0f;
+                if (u > 1.f / dd) t = iRay.t1;
+                else transmittance *= dd;
+            }
+        }
+    }
+    return v3_add(result, v3_scale(opt3(o->backgroundColor), transmittance)); /* :94 */
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* render loop (REF integrators/BaseIntegrator.cpp)                                      */
 /* ------------------------------------------------------------------------------------ */
 
@@ -1160,6 +1255,8 @@ static v3 cast_ray(path_ctx* d, int integrator)
     case VR_INTEGRATOR_HOMOGENEOUS_RAY_MARCHER_NEE:      return cast_ray_marcher(d, 0);
     case VR_INTEGRATOR_HOMOGENEOUS_RAY_MARCHER_IMPROVED: return cast_ray_marcher(d, 1);
     case VR_INTEGRATOR_RATIO_TRACKING:                   return cast_ray_ratio(d);
+    case VR_INTEGRATOR_NANOVDB_SIMPLE:                   return cast_ray_grid_marcher(d, 0);
+    case VR_INTEGRATOR_NANOVDB_EMISSION:                 return cast_ray_grid_marcher(d, 1);
     default:                                             return cast_ray_delta(d);
     }
 }
@@ -1167,7 +1264,10 @@ static v3 cast_ray(path_ctx* d, int integrator)
 static int scene_ok(const vro_scene* sc, int integrator)
 {
     if (integrator < 0 || integrator >= VR_INTEGRATOR_COUNT) return VR_ERR_INVALID_ARG;
-    if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) { if (!sc->density) return VR_ERR_NO_DENSITY; }
+    if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
+        if (!sc->density) return VR_ERR_NO_DENSITY;
+        if (integrator == VR_INTEGRATOR_NANOVDB_EMISSION && !sc->temperature) return VR_ERR_NO_DENSITY; /* Emission :13-18 exits */
+    }
     else if (!sc->mesh) return VR_ERR_NO_MESH;
     return VR_OK;
 }

@@ -76,6 +76,7 @@ int   vro_world_ray_to_index_clip(const vr_grid_desc* g, const float eye[3], con
 int   vro_index_ray_clip(const vr_grid_desc* g, const float eye[3], const float dir[3], float out[8]);
 /* acc.getValue(Coord::Floor(p)) */
 float vro_grid_value_at(const vr_grid_desc* g, const float p[3]);
+void  vro_index_to_world(const vr_grid_desc* g, const float* p_xyz, int n, float* out_xyz);
 float vro_grid_max(const vr_grid_desc* g);
 
 float vro_henyey_greenstein(float g, float cos_theta);

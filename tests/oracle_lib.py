@@ -80,6 +80,8 @@ def lib():
     L.vro_index_ray_clip.restype = C.c_int
     L.vro_grid_value_at.argtypes = [C.POINTER(GridDesc), _pf]
     L.vro_grid_value_at.restype = _f
+    L.vro_index_to_world.argtypes = [C.POINTER(GridDesc), _pf, C.c_int, _pf]
+    L.vro_index_to_world.restype = None
     L.vro_grid_max.argtypes = [C.POINTER(GridDesc)]
     L.vro_grid_max.restype = _f
     L.vro_henyey_greenstein.argtypes = [_f, _f]

@@ -40,7 +40,9 @@ def ref():
     L.refk_grid_values.argtypes = [C.c_void_p, pf, C.c_int, pf]
     L.refk_grid_destroy.argtypes = [C.c_void_p]
     L.refk_bridge_grid.restype = C.c_longlong
-    L.refk_bridge_grid.argtypes = [C.c_void_p, pi, pi, pf, pf, pf, pf, C.c_longlong]
+    L.refk_bridge_grid.argtypes = [C.c_void_p, pi, pi, pf, pf, pf, pf, C.c_longlong, pf]
+    L.refk_grid_mat.argtypes = [C.c_void_p, pf]
+    L.refk_index_to_world.argtypes = [C.c_void_p, pf, C.c_int, pf]
     L.refk_bridge_obj.argtypes = [C.c_char_p, C.c_char_p, pu, pf, pu, pu, pf]
     return L
 
@@ -65,12 +67,14 @@ def test_describe_grid_is_what_the_accessor_returns(ref, oracle, shape, bmin, vs
         ref.refk_grid_info(h, rb0.ctypes.data_as(pi), rb1.ctypes.data_as(pi), fp(mm), fp(inv), fp(vec), fp(bg))
         # the bridge's description of the same grid
         g0, g1 = np.zeros(3, np.int32), np.zeros(3, np.int32)
-        ginv, gvec, gbm = np.zeros(9, f32), np.zeros(3, f32), np.zeros(2, f32)
-        n = ref.refk_bridge_grid(h, g0.ctypes.data_as(pi), g1.ctypes.data_as(pi), fp(ginv), fp(gvec), fp(gbm), None, 0)
+        ginv, gvec, gbm, gmat, rmat = np.zeros(9, f32), np.zeros(3, f32), np.zeros(2, f32), np.zeros(9, f32), np.zeros(9, f32)
+        n = ref.refk_bridge_grid(h, g0.ctypes.data_as(pi), g1.ctypes.data_as(pi), fp(ginv), fp(gvec), fp(gbm), None, 0, fp(gmat))
         dims = g1 - g0 + 1
         assert n == int(np.prod(dims))
         vox = np.zeros(n, dtype=f32)
-        assert ref.refk_bridge_grid(h, g0.ctypes.data_as(pi), g1.ctypes.data_as(pi), fp(ginv), fp(gvec), fp(gbm), fp(vox), n) == n
+        assert ref.refk_bridge_grid(h, g0.ctypes.data_as(pi), g1.ctypes.data_as(pi), fp(ginv), fp(gvec), fp(gbm), fp(vox), n, fp(gmat)) == n
+        ref.refk_grid_mat(h, fp(rmat))
+        assert np.array_equal(gmat.view(np.uint32), rmat.view(np.uint32)) and gmat[0] == f32(vs)
         assert np.array_equal(g0, rb0) and np.array_equal(g1, rb1)
         assert rb0[0] == b0[0] + 1
         assert np.array_equal(ginv.view(np.uint32), inv.view(np.uint32)) and np.array_equal(gvec.view(np.uint32), vec.view(np.uint32))
@@ -82,7 +86,7 @@ def test_describe_grid_is_what_the_accessor_returns(ref, oracle, shape, bmin, vs
         assert np.array_equal(vox.view(np.uint32), crop.view(np.uint32))
         # and a lookup through that description (oracle = what the GPU path reproduces bit for bit) is the
         # reference's getValue(Coord::Floor(p)) — inside, in holes, outside the bbox
-        grid = Grid(vox, bbox_min=g0, inv_mat=ginv, vec=gvec, background=float(gbm[0]), max_value=float(gbm[1]))
+        grid = Grid(vox, bbox_min=g0, inv_mat=ginv, vec=gvec, mat=gmat, background=float(gbm[0]), max_value=float(gbm[1]))
         pos = rng.uniform(b0.astype(f32) - 3, b1.astype(f32) + 4, size=(400, 3)).astype(f32)
         pos[:50] = np.round(pos[:50])
         want = np.zeros(len(pos), dtype=f32)
@@ -90,6 +94,12 @@ def test_describe_grid_is_what_the_accessor_returns(ref, oracle, shape, bmin, vs
         got = np.array([oracle.vro_grid_value_at(C.byref(grid.desc), ol.fptr(np.ascontiguousarray(q))) for q in pos], dtype=f32)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         assert oracle.vro_grid_max(C.byref(grid.desc)) == mm[1]
+        # index -> world (the grid marchers' light-ray origin, IntegratorNanoVDBSimple.cpp:41)
+        wref, wgot = np.zeros((64, 3), f32), np.zeros((64, 3), f32)
+        ipos = np.ascontiguousarray(pos[:64])
+        ref.refk_index_to_world(h, fp(ipos), 64, fp(wref))
+        oracle.vro_index_to_world(C.byref(grid.desc), fp(ipos), 64, fp(wgot))
+        assert np.array_equal(wgot.view(np.uint32), wref.view(np.uint32))
     finally:
         ref.refk_grid_destroy(h)
 

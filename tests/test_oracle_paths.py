@@ -238,3 +238,37 @@ def test_improved_marcher_reference_rng_and_philox_agree_statistically(oracle):
     a = ol.render(sc, o, IMPROVED, rng_mode=ol.RNG_PHILOX, seed=3)
     b = ol.render(sc, o, IMPROVED, rng_mode=ol.RNG_REFERENCE)
     assert abs(a.mean() - b.mean()) / b.mean() < 0.01
+
+
+def test_grid_marcher_transmittance_and_emission_on_a_homogeneous_box(oracle):
+    """nanoVDBSimple / nanoVDBEmission on a constant box: half-voxel steps, sigma = value * 0.5 (Simple)
+    or * 64 (Emission); with a black light the result is background * exp(-0.5 * sigma)^steps
+    (+ emission for the second), steps = number of t in [t0, t1) at stride 0.5."""
+    n, v = 16, 0.2
+    g = Grid(np.full((n, n, n), v, dtype=f32))                     # voxel size 1, bbox [-8, 7]
+    sc, _ = ol.make_scene(density=g)
+    o = default_options(width=5, height=5, widthReference=5, heightReference=5, rayPerPixelCount=1, fov=4.0,
+                        cameraPosition=(0.3, 0.2, 40.0), lightPosition=(0.0, 1.0, 0.0), lightColor=(0.0, 0.0, 0.0),
+                        backgroundColor=(0.5, 0.7, 0.9), heyneyGreensteinG=0.3)
+    img, st = ol.render(sc, o, 4, want_stats=True)
+    bg = np.array(o.backgroundColor[:], dtype=f32)
+    # chord of 16 voxels (ray along -z) at stride 0.5 = 32 samples, the first of which sits exactly on the
+    # entry face z = 8 = bbox.max + 1, i.e. outside the grid (background 0): 31 attenuating steps
+    steps = 2 * n - 1
+    want = bg * math.exp(-0.5 * (v * 0.5) * steps)
+    assert np.allclose(img[2, 2], want, rtol=1e-4), (img[2, 2], want)
+    # one density lookup per step, and per step a light march of ceil(t1 / 10) lookups
+    assert st["density_lookups"] > 25 * steps and 25 * (steps - 1) <= st["shadow_rays"] <= 25 * (steps + 2)
+    lit = ol.render(sc, copy_options(o, lightColor=(1.0, 1.0, 1.0)), 4)
+    assert np.all(lit[2, 2] > img[2, 2])
+    # emission variant needs a temperature grid (the reference exits without one)
+    with pytest.raises(RuntimeError):
+        ol.render(sc, o, 5)
+    t = Grid(np.full((n, n, n), 0.01, dtype=f32))
+    sce, _ = ol.make_scene(density=Grid(np.full((n, n, n), 0.001, dtype=f32)), temperature=t)
+    oe = copy_options(o, emissionColor=(1.0, 0.5, 0.25))
+    e = ol.render(sce, oe, 5)[2, 2]
+    sig = 0.001 * 64.0
+    T = np.cumprod(np.full(steps, math.exp(-0.5 * sig)))
+    want_e = bg * T[-1] + np.array([1.0, 0.5, 0.25]) * (0.01 * 4.0) * 0.5 * T.sum()
+    assert np.allclose(e, want_e, rtol=1e-4), (e, want_e)

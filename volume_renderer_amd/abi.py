@@ -13,6 +13,8 @@ INTEGRATORS = {
     "homogeneousRayMarcherImproved": 1,
     "ratioTracking": 2,
     "deltaTracking": 3,
+    "nanoVDBSimple": 4,
+    "nanoVDBEmission": 5,
 }
 
 VR_OK = 0
@@ -71,6 +73,7 @@ class GridDesc(C.Structure):
         ("bbox_max", C.c_int32 * 3),
         ("inv_mat", C.c_float * 9),
         ("vec", F3),
+        ("mat", C.c_float * 9),
         ("background", C.c_float),
         ("max_value", C.c_float),
     ]
@@ -155,7 +158,7 @@ class Grid:
     """Owns the numpy voxel array behind a GridDesc (keeps it alive)."""
 
     def __init__(self, voxels, bbox_min=None, voxel_size=1.0, origin=(0.0, 0.0, 0.0), background=0.0,
-                 max_value=-1.0, inv_mat=None, vec=None):
+                 max_value=-1.0, inv_mat=None, vec=None, mat=None):
         self.voxels = np.ascontiguousarray(voxels, dtype=np.float32)
         assert self.voxels.ndim == 3
         nx, ny, nz = self.voxels.shape
@@ -168,6 +171,12 @@ class Grid:
         for i in range(3):
             d.bbox_min[i] = self.bbox_min[i]
             d.bbox_max[i] = self.bbox_max[i]
+        if mat is None:
+            if inv_mat is None:
+                vsz = np.float32(voxel_size)
+                mat = [vsz, 0, 0, 0, vsz, 0, 0, 0, vsz]
+            else:   # callers that have the Map's own mMatF pass it; this is only a numerical stand-in
+                mat = np.linalg.inv(np.asarray(inv_mat, dtype=np.float64).reshape(3, 3)).astype(np.float32).ravel()
         if inv_mat is None:
             inv = np.float32(1.0 / float(voxel_size))
             inv_mat = [inv, 0, 0, 0, inv, 0, 0, 0, inv]
@@ -175,6 +184,7 @@ class Grid:
             vec = origin
         for i in range(9):
             d.inv_mat[i] = inv_mat[i]
+            d.mat[i] = mat[i]
         for i in range(3):
             d.vec[i] = vec[i]
         d.background = background

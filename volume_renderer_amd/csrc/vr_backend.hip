@@ -256,7 +256,7 @@ struct vr_backend {
     bool     has_density = false, has_temperature = false;
     float*   d_bricks = nullptr;  float* d_skip = nullptr;  GridDev grid{};   // d_skip: see k_skip_pass
     float*   d_tbricks = nullptr; GridDev tgrid{};
-    float    inv_mat[9]{}, vec[3]{};
+    float    inv_mat[9]{}, vec[3]{}, mat[9]{};
     float    bmin[3]{}, bmax1[3]{};
     float    max_value = 0.0f;
 
@@ -395,9 +395,10 @@ int build_derived(vr_backend* b)
     return VR_OK;
 }
 
-void set_map(vr_backend* b, const float* inv_mat, const float* vec, const int32_t* bmin, const int32_t* bmax)
+void set_map(vr_backend* b, const float* inv_mat, const float* vec, const float* mat, const int32_t* bmin, const int32_t* bmax)
 {
     memcpy(b->inv_mat, inv_mat, sizeof b->inv_mat);
+    memcpy(b->mat, mat, sizeof b->mat);
     memcpy(b->vec, vec, sizeof b->vec);
     for (int i = 0; i < 3; ++i) { b->bmin[i] = (float)bmin[i]; b->bmax1[i] = (float)(bmax[i] + 1); }   // Ray.h:401
 }
@@ -528,7 +529,11 @@ int validate(vr_backend* b, const vr_options_pod* o, int integrator)
     if (o->width + o->widthStartOffset > 65536u || o->height + o->heightStartOffset > 65536u)
         return fail(b, VR_ERR_INVALID_ARG, "image coordinates must stay below 65536 (Philox pixel key)");
     if (o->maxDepth > 255) return fail(b, VR_ERR_INVALID_ARG, "maxDepth is a uint8_t in the reference (Types.h:101)");
-    if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
+    if (integrator == VR_INTEGRATOR_NANOVDB_SIMPLE || integrator == VR_INTEGRATOR_NANOVDB_EMISSION) {
+        if (!b->has_density) return fail(b, VR_ERR_NO_DENSITY, "the grid marchers need a density grid (SceneLoader.cpp:212-213)");
+        if (integrator == VR_INTEGRATOR_NANOVDB_EMISSION && !b->has_temperature)
+            return fail(b, VR_ERR_NO_DENSITY, "nanoVDBEmission needs a temperature grid (IntegratorNanoVDBEmission.cpp:13-18 exits)");
+    } else if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
         if (!b->has_density) return fail(b, VR_ERR_NO_DENSITY, "tracking integrators need a density grid (SceneLoader.cpp:212-213)");
         // every step must advance t in float, or the reference's loops never end
         if (!(o->stepSizeMin > 0.0f) || !(o->stepSizeMax >= o->stepSizeMin))
@@ -585,7 +590,8 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
 
     // the voxel-span / empty-run estimates assume ray parameters of at most a few thousand voxels
     bool span_ok = true;
-    if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) span_ok = tracking_t_max(b, o) < 8000.0f;
+    const bool tracking = integrator == VR_INTEGRATOR_RATIO_TRACKING || integrator == VR_INTEGRATOR_DELTA_TRACKING;
+    if (tracking) span_ok = tracking_t_max(b, o) < 8000.0f;
     b->cold_host.clear();
     b->cold_host.reserve(spp + 1);
 
@@ -611,7 +617,27 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
         Pass& ev = b->passes[b->passes_used++];
         HIP_TRY(b, hipMemsetAsync(b->d_work, 0, sizeof(uint32_t), b->stream));
 
-        if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
+        if (integrator == VR_INTEGRATOR_NANOVDB_SIMPLE || integrator == VR_INTEGRATOR_NANOVDB_EMISSION) {
+            GridMarchParams p{};
+            p.cam = cam; p.work = work;
+            p.density = b->grid; p.temperature = b->tgrid;
+            memcpy(p.inv_mat, b->inv_mat, sizeof p.inv_mat); memcpy(p.vec, b->vec, sizeof p.vec); memcpy(p.mat, b->mat, sizeof p.mat);
+            memcpy(p.bmin, b->bmin, sizeof p.bmin); memcpy(p.bmax1, b->bmax1, sizeof p.bmax1);
+            p.g = o->heyneyGreensteinG;
+            for (int i = 0; i < 3; ++i) {
+                p.light[i] = o->lightPosition[i]; p.light_color[i] = o->lightColor[i];
+                p.emission[i] = o->emissionColor[i]; p.background[i] = o->backgroundColor[i];
+            }
+            void (*kern)(const GridMarchParams) =
+                integrator == VR_INTEGRATOR_NANOVDB_SIMPLE
+                    ? (exact ? vr_gridmarch_kernel<false, true> : vr_gridmarch_kernel<false, false>)
+                    : (exact ? vr_gridmarch_kernel<true, true> : vr_gridmarch_kernel<true, false>);
+            const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(8ull * b->num_cu, (work.nitems + 255ull) / 256));
+            HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
+            HIP_TRY(b, hipGetLastError());
+            HIP_TRY(b, hipEventRecord(ev.e1, b->stream));
+        } else if (tracking) {
             TrackCold cold{};
             cold.cam = cam;
             memcpy(cold.inv_mat, b->inv_mat, sizeof cold.inv_mat); memcpy(cold.vec, b->vec, sizeof cold.vec);
@@ -794,7 +820,7 @@ int vr_backend_set_density(vr_backend* b, const vr_grid_desc* density, const vr_
     b->has_density = false; b->has_temperature = false;
     rc = upload_grid(b, density, b->d_bricks, b->grid);
     if (rc) return rc;
-    set_map(b, density->inv_mat, density->vec, density->bbox_min, density->bbox_max);
+    set_map(b, density->inv_mat, density->vec, density->mat, density->bbox_min, density->bbox_max);
     rc = build_derived(b);
     if (rc) return rc;
     if (density->max_value >= 0.0f) b->max_value = density->max_value;   // the caller's getExtrema result
@@ -829,7 +855,7 @@ int vr_backend_generate_cloud(vr_backend* b, int n, float radius_voxels)
     }
     b->grid.background = 0.0f;
     const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, zero[3] = { 0, 0, 0 };
-    set_map(b, ident, zero, bmin, bmax);
+    set_map(b, ident, zero, ident, bmin, bmax);
     rc = build_derived(b);
     if (rc) return rc;
     b->has_density = true;

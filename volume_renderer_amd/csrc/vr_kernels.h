@@ -5,6 +5,8 @@
 //   vr_march_kernel<IMPROVED, EXACT> fixed-step marchers through a mesh-bounded medium
 //                                  (IntegratorHomogeneousRayMarcherNEE.cpp:10-118,
 //                                   IntegratorHomogeneousRayMarcherImproved.cpp:11-149)
+//   vr_gridmarch_kernel<EMISSION, EXACT> fixed-step marchers through the grid
+//                                  (IntegratorNanoVDBSimple.cpp:10-95, IntegratorNanoVDBEmission.cpp:10-110)
 //   vr_resolve_kernel              per-pixel ordered sum over samples (BaseIntegrator.cpp:71,92,108)
 //
 // Work decomposition: one path sample (one castRay call) per lane.  Items are numbered
@@ -768,6 +770,131 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&p.work.counters->path_samples, a);
         atomicAdd(&p.work.counters->ray_queries, b);
+        atomicAdd(&p.work.counters->shadow_rays, c);
+    }
+}
+
+// =============================================================================================
+// fixed-step marchers through the voxel grid
+// =============================================================================================
+// IntegratorNanoVDBSimple::castRay (IntegratorNanoVDBSimple.cpp:10-95) and
+// IntegratorNanoVDBEmission::castRay (IntegratorNanoVDBEmission.cpp:10-110): half-voxel steps along the
+// clipped index-space ray, at every non-empty step a 10-voxel-step march toward the light.  One path
+// sample per lane, grid-stride; deterministic but for the roulette at transmittance < 1e-3.
+struct GridMarchParams {
+    CameraDev cam;
+    WorkDev   work;
+    GridDev   density, temperature;
+    float     inv_mat[9], vec[3], mat[9];
+    float     bmin[3], bmax1[3];
+    float     g;
+    float     light[3], light_color[3], emission[3], background[3];
+};
+
+template <bool EMISSION, bool EXACT>
+__global__ void __launch_bounds__(256) vr_gridmarch_kernel(const GridMarchParams p)
+{
+    typedef Math<EXACT> M;
+    const uint32_t k0 = p.work.key0, k1 = p.work.key1;
+    unsigned long long n_lookups = 0;
+    uint32_t n_paths = 0, n_light = 0;
+    const f3 light = mk3(p.light[0], p.light[1], p.light[2]);
+    const f3 light_color = mk3(p.light_color[0], p.light_color[1], p.light_color[2]);
+    const f3 bg = mk3(p.background[0], p.background[1], p.background[2]);
+    // the light ray's index-space direction does not depend on the sample        Ray.h:257-267
+    const f3    l_idir = mat_mult(p.inv_mat, light);
+    const float l_length = sqrtf(l_idir.x * l_idir.x + l_idir.y * l_idir.y + l_idir.z * l_idir.z);
+    const float l_inv_length = 1.0f / l_length;
+    const f3    l_dir = mk3(l_inv_length * l_idir.x, l_inv_length * l_idir.y, l_inv_length * l_idir.z);
+
+    for (uint32_t mine = blockIdx.x * blockDim.x + threadIdx.x; mine < p.work.nitems; mine += gridDim.x * blockDim.x) {
+        const uint32_t x = mine % p.cam.width;
+        const uint32_t q = mine / p.cam.width;
+        const uint32_t r = q % p.cam.nrows;
+        const uint32_t s = p.cam.s_first + q / p.cam.nrows;
+        const uint32_t ci = p.cam.x0 + x;
+        const uint32_t cj = p.cam.y0 + p.cam.row_first + r * p.cam.row_stride;
+        n_paths++;
+        const uint32_t rng_pixel = (cj << 16) | ci;
+
+        const f3 wdir = primary_direction(p.cam, ci, cj, s);
+        const f3 ray_direction = normalize3(wdir);                                  // Simple :12
+        const f3 weye = mk3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+        const f3 ieye = mat_mult(p.inv_mat, mk3(weye.x - p.vec[0], weye.y - p.vec[1], weye.z - p.vec[2]));   // :15-20
+        const f3 idir = mat_mult(p.inv_mat, wdir);
+        const float length = sqrtf(idir.x * idir.x + idir.y * idir.y + idir.z * idir.z);
+        const float inv_length = 1.0f / length;
+        const f3 ndir = mk3(inv_length * idir.x, inv_length * idir.y, inv_length * idir.z);
+        float c0 = length * 1e-5f, c1 = VR_FLT_MAX;
+        f3 result = bg;
+        if (ray_clip(ieye, ndir, c0, c1, p.bmin, p.bmax1)) {                        // :22-24
+            const float density = EMISSION ? 64.0f : 0.5f;                          // Simple :25, Emission :35
+            const float light_ray_density = density * 0.5f;                         // :26
+            const float step_size = 0.5f;                                           // :28
+            float transmittance = 1.0f;                                             // :30
+            f3 acc = mk3(0, 0, 0);                                                  // :32
+            uint32_t n = 0;
+            for (float t = c0; t < c1; t += step_size, ++n) {                       // :34
+                const f3 ip = ray_at(ieye, ndir, t);
+                const float sigma = grid_value_nocache(p.density, ip) * density;    // :36
+                n_lookups++;
+                float emission_value = 0.0f;
+                if (EMISSION) {                                                     // Emission :47-48
+                    emission_value = grid_value_nocache(p.temperature, ip) * 4.0f;
+                    n_lookups++;
+                }
+                transmittance *= M::exp_(-step_size * sigma);                       // :38-40
+                if (sigma > 0 || (EMISSION && emission_value > 0)) {                // Simple :47, Emission :61
+                    // castLightRay (:97-128): from the sample's WORLD position (:42-45) toward the light
+                    const f3 world = mk3(fmaf(ip.x, p.mat[0], fmaf(ip.y, p.mat[1], fmaf(ip.z, p.mat[2], p.vec[0]))),
+                                         fmaf(ip.x, p.mat[3], fmaf(ip.y, p.mat[4], fmaf(ip.z, p.mat[5], p.vec[1]))),
+                                         fmaf(ip.x, p.mat[6], fmaf(ip.y, p.mat[7], fmaf(ip.z, p.mat[8], p.vec[2]))));
+                    const f3 leye = mat_mult(p.inv_mat, mk3(world.x - p.vec[0], world.y - p.vec[1], world.z - p.vec[2]));
+                    float l0 = l_length * 1e-5f, l1 = VR_FLT_MAX;
+                    n_light++;
+                    if (ray_clip(leye, l_dir, l0, l1, p.bmin, p.bmax1)) {           // :49
+                        float tau = 0;
+                        const float light_step_size = step_size * 20.0f;            // :52
+                        const float num_steps_light = ceilf(l1 / light_step_size);  // :53 (t1, not t1 - t0)
+                        for (uint32_t nl = 0; (float)nl < num_steps_light; ++nl) {  // :55
+                            const float t_light = (float)((double)light_step_size * ((double)nl + 0.5));   // :56
+                            tau += grid_value_nocache(p.density, ray_at(leye, l_dir, l0 + t_light)) * light_ray_density;   // :57
+                            n_lookups++;
+                        }
+                        const float cos_theta = dot3(ray_direction, light);         // :60
+                        const float light_attenuation = M::exp_(-tau * light_step_size * sigma);   // :61
+                        f3 c = scale3(light_color, light_attenuation);              // :63-69
+                        c = scale3(c, sigma);
+                        c = scale3(c, hg_phase(p.g, cos_theta));
+                        c = scale3(c, transmittance);
+                        c = scale3(c, step_size);
+                        acc = add3(acc, c);
+                    } else {                                                        // :73-78
+                        f3 c = scale3(light_color, sigma);
+                        c = scale3(c, transmittance);
+                        c = scale3(c, step_size);
+                        acc = add3(acc, c);
+                    }
+                    if (EMISSION) {                                                 // Emission :48, :90
+                        const f3 emission = scale3(mk3(p.emission[0], p.emission[1], p.emission[2]), emission_value);
+                        acc = add3(acc, scale3(scale3(emission, transmittance), step_size));
+                    }
+                    if ((double)transmittance < 1e-3) {                             // :81-89
+                        uint32_t w0, w1, w2, w3;
+                        philox4x32_10(rng_pixel, s, 0u, n, k0, k1, w0, w1, w2, w3);
+                        if (in_range(w1, 0, 1) > 1.f / 2) t = c1;
+                        else transmittance *= 2;
+                    }
+                }
+            }
+            result = add3(acc, scale3(bg, transmittance));                          // :94
+        }
+        store_sample(p.work.samples, mine, result);
+    }
+    unsigned long long a = wave_sum(n_paths), b = wave_sum(n_lookups), c = wave_sum(n_light);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&p.work.counters->path_samples, a);
+        atomicAdd(&p.work.counters->density_lookups, b);
         atomicAdd(&p.work.counters->shadow_rays, c);
     }
 }

@@ -4,7 +4,7 @@
 // integrators/IntegratorFactory.cpp:12-24) and drives it through
 //   BaseIntegrator::render(Options&, SceneInfo*)                                 (BaseIntegrator.h:69)
 //   BaseIntegrator::renderPartial(Vec3f* orig, Vec3f* pix, ThreadInfo*, const Options&, SceneInfo*)  (:67)
-// This header keeps those names and argument meanings for the four integrators on the GPU path
+// This header keeps those names and argument meanings for the integrators on the GPU path
 // and forwards to include/vr_backend.h.  Options / SceneInfo here are the POD subsets the path
 // reads (vr_options_pod, vr_grid_desc, vr_mesh_desc); INTEGRATION.md shows how the reference's own
 // structs map onto them.  Header-only, C++17, links libvr_backend.so only.
@@ -104,6 +104,8 @@ struct IntegratorFactory {
             { "homogeneousRayMarcherImproved", VR_INTEGRATOR_HOMOGENEOUS_RAY_MARCHER_IMPROVED },
             { "ratioTracking", VR_INTEGRATOR_RATIO_TRACKING },
             { "deltaTracking", VR_INTEGRATOR_DELTA_TRACKING },
+            { "nanoVDBSimple", VR_INTEGRATOR_NANOVDB_SIMPLE },
+            { "nanoVDBEmission", VR_INTEGRATOR_NANOVDB_EMISSION },
         };
         for (const auto& e : table)
             if (name == e.name) return std::make_unique<BaseIntegrator>(e.id);

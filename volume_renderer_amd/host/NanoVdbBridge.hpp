@@ -49,9 +49,10 @@ inline void describeGrid(const GridT& grid, const BBoxT& bbox, float max_value, 
         for (int j = d.bbox_min[1]; j <= d.bbox_max[1]; ++j)
             for (int k = d.bbox_min[2]; k <= d.bbox_max[2]; ++k) out.voxels[o++] = acc.getValue(CoordT(i, j, k));
     d.voxels = out.voxels.data();
-    // index = mInvMatF * (world - mVecF): the members Map::applyInverseMapF reads (NanoVDB.h:2262-2270)
+    // index = mInvMatF * (world - mVecF), world = mMatF * index + mVecF: the members Map::applyInverseMapF /
+    // applyMapF read (NanoVDB.h:2262-2270, :2249)
     const auto& m = grid.map();
-    for (int a = 0; a < 9; ++a) d.inv_mat[a] = m.mInvMatF[a];
+    for (int a = 0; a < 9; ++a) { d.inv_mat[a] = m.mInvMatF[a]; d.mat[a] = m.mMatF[a]; }
     for (int a = 0; a < 3; ++a) d.vec[a] = m.mVecF[a];
     d.background = grid.tree().background();
     d.max_value = max_value;
