@@ -654,7 +654,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             TrackParams p{};
             p.cold = b->d_cold; p.work = work;
             p.density = b->grid; p.has_temperature = b->has_temperature ? 1 : 0;
-            p.importance = o->useImportanceSampling ? 1 : 0;
+            const bool is = o->useImportanceSampling != 0;
             p.sigma_a = o->sigma_a; p.sigma_s = o->sigma_s;
             p.sigma_maj = b->max_value * (o->sigma_a + o->sigma_s);          // IntegratorRatioTracking.cpp:42-45
             p.t_min = o->stepSizeMin; p.t_max = o->stepSizeMax; p.step_mult = o->stepSizeMultiplier;
@@ -673,12 +673,15 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             // multipliers >= 0 (the shadow multiplier is only read by the ratio tracker)
             const bool skip_ok = span_ok && o->lightRayDensityMultiplier >= 0.0f && (!ratio || o->shadowRayDensityMultiplier >= 0.0f);
             if (skip_ok && b->mode != VR_MODE_EXACT) p.density.bricks = b->d_skip;
+#define VR_TRACK_KERNEL(E, S) (ratio ? (is ? vr_track_kernel<INTEG_RATIO, E, S, true> : vr_track_kernel<INTEG_RATIO, E, S, false>) \
+                                     : (is ? vr_track_kernel<INTEG_DELTA, E, S, true> : vr_track_kernel<INTEG_DELTA, E, S, false>))
             switch (skip_ok ? b->mode : (b->mode == VR_MODE_FAST ? -1 : VR_MODE_EXACT)) {
-            case -1:                 kern = ratio ? vr_track_kernel<INTEG_RATIO, false, false> : vr_track_kernel<INTEG_DELTA, false, false>; break;
-            case VR_MODE_EXACT:      kern = ratio ? vr_track_kernel<INTEG_RATIO, true, false> : vr_track_kernel<INTEG_DELTA, true, false>; break;
-            case VR_MODE_EXACT_SKIP: kern = ratio ? vr_track_kernel<INTEG_RATIO, true, true> : vr_track_kernel<INTEG_DELTA, true, true>; break;
-            default:                 kern = ratio ? vr_track_kernel<INTEG_RATIO, false, true> : vr_track_kernel<INTEG_DELTA, false, true>; break;
+            case -1:                 kern = VR_TRACK_KERNEL(false, false); break;
+            case VR_MODE_EXACT:      kern = VR_TRACK_KERNEL(true, false); break;
+            case VR_MODE_EXACT_SKIP: kern = VR_TRACK_KERNEL(true, true); break;
+            default:                 kern = VR_TRACK_KERNEL(false, true); break;
             }
+#undef VR_TRACK_KERNEL
             int per_cu = 4;
             rc = launch_cap(b, kern, p, per_cu);
             if (rc) return rc;
