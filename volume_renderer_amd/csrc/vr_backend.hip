@@ -653,7 +653,8 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             HIP_TRY(b, hipMemcpyAsync(b->d_cold, &b->cold_host.back(), sizeof(TrackCold), hipMemcpyHostToDevice, b->stream));
             TrackParams p{};
             p.cold = b->d_cold; p.work = work;
-            p.density = b->grid; p.has_temperature = b->has_temperature ? 1 : 0;
+            p.density = b->grid;
+            const bool temp = b->has_temperature;
             const bool is = o->useImportanceSampling != 0;
             p.sigma_a = o->sigma_a; p.sigma_s = o->sigma_s;
             p.sigma_maj = b->max_value * (o->sigma_a + o->sigma_s);          // IntegratorRatioTracking.cpp:42-45
@@ -662,10 +663,11 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             p.round_max = tune_int("VR_TUNE_ROUND_MAX", VR_ROUND_MAX);
             p.round_events = tune_int("VR_TUNE_ROUND_EVENTS", VR_ROUND_EVENTS);
             // typical free path (index units) well under a voxel: remember each voxel's t-interval
+            bool span = false;
             {
                 const float mean_free = p.sigma_maj > 0.0f ? o->stepSizeMultiplier / p.sigma_maj : 1e30f;
                 const float typical = std::min(std::max(o->stepSizeMin, mean_free), o->stepSizeMax);
-                p.use_span = (typical < 0.25f && span_ok) ? 1 : 0;
+                span = typical < 0.25f && span_ok;
             }
             void (*kern)(const TrackParams);
             const bool ratio = integrator == VR_INTEGRATOR_RATIO_TRACKING;
@@ -673,14 +675,17 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             // multipliers >= 0 (the shadow multiplier is only read by the ratio tracker)
             const bool skip_ok = span_ok && o->lightRayDensityMultiplier >= 0.0f && (!ratio || o->shadowRayDensityMultiplier >= 0.0f);
             if (skip_ok && b->mode != VR_MODE_EXACT) p.density.bricks = b->d_skip;
-#define VR_TRACK_KERNEL(E, S) (ratio ? (is ? vr_track_kernel<INTEG_RATIO, E, S, true> : vr_track_kernel<INTEG_RATIO, E, S, false>) \
-                                     : (is ? vr_track_kernel<INTEG_DELTA, E, S, true> : vr_track_kernel<INTEG_DELTA, E, S, false>))
+#define VR_TK4(I, E, S, Q) (temp ? (span ? vr_track_kernel<I, E, S, Q, true, true> : vr_track_kernel<I, E, S, Q, true, false>) \
+                                 : (span ? vr_track_kernel<I, E, S, Q, false, true> : vr_track_kernel<I, E, S, Q, false, false>))
+#define VR_TRACK_KERNEL(E, S) (ratio ? (is ? VR_TK4(INTEG_RATIO, E, S, true) : VR_TK4(INTEG_RATIO, E, S, false)) \
+                                     : (is ? VR_TK4(INTEG_DELTA, E, S, true) : VR_TK4(INTEG_DELTA, E, S, false)))
             switch (skip_ok ? b->mode : (b->mode == VR_MODE_FAST ? -1 : VR_MODE_EXACT)) {
             case -1:                 kern = VR_TRACK_KERNEL(false, false); break;
             case VR_MODE_EXACT:      kern = VR_TRACK_KERNEL(true, false); break;
             case VR_MODE_EXACT_SKIP: kern = VR_TRACK_KERNEL(true, true); break;
             default:                 kern = VR_TRACK_KERNEL(false, true); break;
             }
+#undef VR_TK4
 #undef VR_TRACK_KERNEL
             int per_cu = 4;
             rc = launch_cap(b, kern, p, per_cu);

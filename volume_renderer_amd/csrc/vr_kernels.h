@@ -73,8 +73,6 @@ struct TrackParams {
     const TrackCold* cold;
     WorkDev   work;
     GridDev   density;               // SKIP kernels: the skip grid (empty voxels hold -(empty-cube radius + 1))
-    int32_t   has_temperature;
-    int32_t   use_span;              // steps are much shorter than a voxel: remember the voxel's t-interval
     int32_t   round_max, round_events; // step-loop trips per round / waiting lanes that end a round early
     float     sigma_a, sigma_s, sigma_maj;
     float     t_min, t_max, step_mult;
@@ -140,12 +138,22 @@ __device__ __forceinline__ const T* opaque(const T* p)
     return (const T*)v;
 }
 
+// Waves per SIMD the register allocator must allow.  Left alone the FAST kernels use 98-112 VGPRs
+// (4 waves); held to 96 (5 waves, the ratio tracker then spills 32 bytes) they are 8 % faster.
+#ifndef VR_TRACK_WAVES
+#define VR_TRACK_WAVES(INTEG, EXACT) (!(EXACT) ? 5 : 4)
+#endif
+
 // SKIP: take runs of empty-space iterations at once (empty_run, vr_device.h) — same results bit
 // for bit, fewer trips through the loop.
 // IS: Options::useImportanceSampling — track the path pdf and divide the sample by max(0.1, pdf)
 // (a compile-time switch: as a run-time flag it cost the common case 1.3 %).
-template <int INTEG, bool EXACT, bool SKIP, bool IS>
-__global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
+// TEMP: a temperature grid is present (emission lookups); SPAN: steps are much shorter than a voxel,
+// remember the voxel's t-interval.  Compile-time too: as run-time flags in the step loop they cost
+// 2.5 % and 6.5 %.
+template <int INTEG, bool EXACT, bool SKIP, bool IS, bool TEMP, bool SPAN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VR_TRACK_WAVES(INTEG, EXACT), VR_TRACK_WAVES(INTEG, EXACT))))
+vr_track_kernel(const TrackParams p)
 {
     typedef Math<EXACT> M;
     const int      lane = threadIdx.x & 63;
@@ -190,7 +198,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
     // are collected in locals and assigned once at the end: every state variable is then written on
     // every path, which keeps them all in registers.
     auto prefetch = [&]() {
-        if (p.use_span && t < t_span) return;                  // same voxel, nothing to do
+        if (SPAN && t < t_span) return;                  // same voxel, nothing to do
         const f3 q = ray_at(eye, dir, t);
         const float fx = floorf(q.x), fy = floorf(q.y), fz = floorf(q.z);
         const int32_t i = (int32_t)fx - p.density.min[0], j = (int32_t)fy - p.density.min[1], k = (int32_t)fz - p.density.min[2];
@@ -202,7 +210,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
             n_off = brick_offset(p.density, (uint32_t)i, (uint32_t)j, (uint32_t)k);
             n_val = cur_val;
             if (n_off != cur_off) n_val = p.density.bricks[n_off];
-            if (p.use_span || SKIP)
+            if (SPAN || SKIP)
                 // ray parameter at which the walk leaves the voxel shrunk by `slack` on every side (see empty_run)
                 n_span = fminf(fminf((fx + span_off.x) * inv.x, (fy + span_off.y) * inv.y), (fz + span_off.z) * inv.z);
         }
@@ -243,7 +251,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                     if (INTEG == INTEG_RATIO) {                                   // :127-131
                         radiance = add3(radiance, scale3(medium, T));
                     } else {                                                      // delta :101-113
-                        if (p.has_temperature)
+                        if (TEMP)
                             radiance = add3(radiance, scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), scatter_len));
                         radiance = add3(radiance, medium);
                     }
@@ -452,7 +460,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                 // yet nearly every wave has such a lane: it sits out the second half instead and
                 // is served by the lookup at the end of the trip.
                 if (half == 0 && t <= t1) {
-                    if (p.use_span) parked = !(t < t_span);
+                    if (SPAN) parked = !(t < t_span);
                     else prefetch();
                 }
                 if (t > t1) {                                                                 // :91 / :258
@@ -500,7 +508,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                         is_absorb = sample < pNull + pA;
                     }
                     if (INTEG == INTEG_RATIO) T = T * att;
-                    if (INTEG == INTEG_RATIO && p.has_temperature) {                          // :110-122
+                    if (INTEG == INTEG_RATIO && TEMP) {                          // :110-122
                         const TrackCold* c = opaque(p.cold);
                         const float emission = grid_value_nocache(c->temperature, ray_at(eye, dir, t));
                         n_lookups++;
@@ -515,7 +523,7 @@ __global__ void __launch_bounds__(256) vr_track_kernel(const TrackParams p)
                         // null collision
                     } else if (is_absorb) {
                         // absorption: the medium colour is added in the event phase          :127-131 (delta :101-113)
-                        if (INTEG == INTEG_DELTA && p.has_temperature) n_lookups++;           // accEmission.getValue, result unused (delta :103)
+                        if (INTEG == INTEG_DELTA && TEMP) n_lookups++;           // accEmission.getValue, result unused (delta :103)
                         scatter_len = sigma * p.sigma_a;
                         st = ST_ABSORBED;
                     } else {
