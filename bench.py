@@ -65,7 +65,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(integ_id, n, opts, target_seconds):
+def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None):
     """Oracle (port of the reference algorithm) on the host cores, bounded sample of the same frame."""
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
@@ -77,10 +77,13 @@ def cpu_baseline(integ_id, n, opts, target_seconds):
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 64)
     L = ol.lib()
     L.vro_set_math_mode(ol.MATH_LIBM)
-    vox = np.zeros((n, n, n), dtype=np.float32)
-    L.vro_make_cloud(n, scenes.cloud_radius(n), ol.fptr(vox), cores)
-    grid = Grid(vox)
-    scene, _keep = ol.make_scene(density=grid)
+    if mesh is not None:
+        scene, _keep = ol.make_scene(mesh=mesh)
+    else:
+        vox = np.zeros((n, n, n), dtype=np.float32)
+        L.vro_make_cloud(n, scenes.cloud_radius(n), ol.fptr(vox), cores)
+        grid = Grid(vox)
+        scene, _keep = ol.make_scene(density=grid)
     o1 = copy_options(opts, rayPerPixelCount=1)   # 1 sub-sample per pixel, scaled linearly in spp
 
     def rows(row_list):
@@ -235,10 +238,10 @@ def main():
                          "frac measures lookup rate, not HBM traffic (see traffic)"),
             },
         }
-        want_cpu = (a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and world == 1)) and not mesh_scene
+        want_cpu = a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and world == 1)
         if want_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(integ_id, n, opts, a.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(integ_id, n, opts, a.cpu_seconds, mesh if mesh_scene else None)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mpath-samples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
