@@ -48,6 +48,7 @@ WORKLOADS = {
     "config1_marcher_cube_512_1spp": ("homogeneousRayMarcherNEE", "cube", 512, 512, 1, "mesh"),
     "config5_marcher_sphere_4k": ("homogeneousRayMarcherImproved", "icosphere", 3840, 2160, 64, "mesh"),
     "config5_marcher_nee_sphere_4k": ("homogeneousRayMarcherNEE", "icosphere", 3840, 2160, 64, "mesh"),
+    "perlin_marcher_sphere_1080p": ("heterogeneousPerlinNoise", "icosphere", 1920, 1080, 16, "mesh"),
 }
 BVH_NODE_BYTES = 36            # one BvhNode per closest-hit query at the least (vr_kernels.h)
 
@@ -229,7 +230,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S, "traffic": traffic,
-                "kernel": {0: "vr_march_kernel", 1: "vr_march_kernel", 4: "vr_gridmarch_kernel", 5: "vr_gridmarch_kernel"}.get(integ_id, "vr_track_kernel"),
+                "kernel": {0: "vr_march_kernel", 1: "vr_march_kernel", 6: "vr_march_kernel", 4: "vr_gridmarch_kernel", 5: "vr_gridmarch_kernel"}.get(integ_id, "vr_track_kernel"),
                 "kernel_ms_per_launch": avg_launch_s * 1e3, "launches": int(launches_all),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": ("algorithmic bytes = 36 B (one BVH node) x closest-hit queries: a lower bound, the BVH is L2-resident"

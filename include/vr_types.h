@@ -24,7 +24,8 @@ typedef enum vr_integrator_id {
     VR_INTEGRATOR_DELTA_TRACKING                   = 3, /* "deltaTracking"                 */
     VR_INTEGRATOR_NANOVDB_SIMPLE                   = 4, /* "nanoVDBSimple"                 */
     VR_INTEGRATOR_NANOVDB_EMISSION                 = 5, /* "nanoVDBEmission"               */
-    VR_INTEGRATOR_COUNT                            = 6
+    VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE       = 6, /* "heterogeneousPerlinNoise"      */
+    VR_INTEGRATOR_COUNT                            = 7
 } vr_integrator_id;
 
 /* POD mirror of `struct Options` (Utils/Types.h:85-122) without the strings/vectors.

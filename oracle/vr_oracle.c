@@ -1135,6 +1135,67 @@ static v3 march_segment(path_ctx* d, int improved)
     return v3_add(v3_scale(opt3(o->backgroundColor), transparency), result); /* NEE :102 */
 }
 
+/* The march of IntegratorHeterogeneousPerlinNoise::handleIntersection (REF
+ * integrators/IntegratorHeterogeneousPerlinNoise.cpp:62-150): the Improved marcher's walk with the
+ * density read from PerlinNoiseSampler::eval_density at every sample and along every light ray.
+ * Unlike the homogeneous marchers it does NOT rescale the step to distance/ns. */
+static v3 march_segment_perlin(path_ctx* d)
+{
+    const vr_options_pod* o = d->o;
+    float distance = d->tFar;                                               /* :64 */
+    v3 light_dir = opt3(o->lightPosition);
+    v3 light_color = opt3(o->lightColor);
+    float sigma_s = o->sigma_s;
+    float sigma_t = o->sigma_a + o->sigma_s;                                /* :74 */
+    float g = o->heyneyGreensteinG;
+    float step_size = 0.2f;                                                 /* :78 */
+    int ns = (int)ceilf(distance / step_size);                              /* :79 */
+    float transparency = 1;
+    v3 result = v3_make(0, 0, 0);
+    v3 rayDirection = u_normalize(d->rayDirection);                         /* :86 */
+    v3 rayOrigin = d->rayOrigin;
+
+    for (size_t n = 0; n < (size_t)ns; n++) {                               /* :89 */
+        double randomOffset = rng_march_jitter(d->rng, (uint32_t)n);        /* :91-93 */
+        float t = (float)(step_size * (n + randomOffset));                  /* :99 */
+        v3 samplePosition = v3_add(rayOrigin, v3_scale(rayDirection, t));   /* :101 */
+        float sp[3] = { samplePosition.x, samplePosition.y, samplePosition.z };
+        float density = vro_perlin_eval_density(sp);                        /* :103 */
+        d->st->density_lookups++;
+        float sampleAttenuation = m_expf(-step_size * density * sigma_t);   /* :106 */
+        transparency *= sampleAttenuation;                                  /* :109 */
+        d->rayDirection = light_dir;                                        /* :112 */
+        d->rayOrigin = v3_add(samplePosition, v3_scale(d->rayDirection, 0.001f)); /* :113 */
+        if (density > 0 && (d->st->shadow_rays++, cast_single_ray(d))) {    /* :116-117 */
+            float tau = 0;
+            float dl = d->tFar;                                             /* :119 */
+            float num_steps_light = ceilf(dl / step_size);                  /* :120 */
+            for (size_t nl = 0; (float)nl < num_steps_light; ++nl) {        /* :122 */
+                float tLight = (float)(step_size * (nl + 0.5));             /* :123 */
+                v3 pl = v3_add(samplePosition, v3_scale(light_dir, tLight)); /* :124 (float * Vec3f) */
+                float lp[3] = { pl.x, pl.y, pl.z };
+                tau += vro_perlin_eval_density(lp);                         /* :125 */
+                d->st->density_lookups++;
+            }
+            float cos_theta = u_dot(rayDirection, light_dir);               /* :128 */
+            float light_attenuation = m_expf(-tau * step_size * sigma_t);   /* :129 */
+            v3 c = v3_scale(light_color, light_attenuation);                /* :130-137, left to right */
+            c = v3_scale(c, density);
+            c = v3_scale(c, sigma_s);
+            c = v3_scale(c, hg_phase(g, cos_theta));
+            c = v3_scale(c, transparency);
+            c = v3_scale(c, step_size);
+            result = v3_add(result, c);
+            int dd = 2;                                                     /* :140-148 */
+            if (transparency < 1e-3) {
+                if (rng_march_roulette(d->rng) > 1.f / dd) n = (size_t)ns;
+                else transparency *= dd;
+            }
+        }
+    }
+    return v3_add(v3_scale(opt3(o->backgroundColor), transparency), result); /* :153 */
+}
+
 /* castRay + handleIntersection unrolled into a loop
  * (REF IntegratorHomogeneousRayMarcherNEE.cpp:10-118; Improved :11-149 is the same walk). */
 static v3 cast_ray_marcher(path_ctx* d, int improved)
@@ -1148,7 +1209,7 @@ static v3 cast_ray_marcher(path_ctx* d, int improved)
         float dissolve = m->shape_dissolve[d->objectId];                    /* :49 */
         if (dissolve > 0) {                                                 /* :52 */
             if (d->previousObjectId == d->objectId)                         /* :55 */
-                return march_segment(d, improved);
+                return improved == 2 ? march_segment_perlin(d) : march_segment(d, improved);
             d->rayOrigin = v3_add(d->hitPoint, v3_scale(d->rayDirection, 0.001f)); /* :105 */
             continue;                                                       /* :107 */
         }
@@ -1257,6 +1318,7 @@ static v3 cast_ray(path_ctx* d, int integrator)
     case VR_INTEGRATOR_RATIO_TRACKING:                   return cast_ray_ratio(d);
     case VR_INTEGRATOR_NANOVDB_SIMPLE:                   return cast_ray_grid_marcher(d, 0);
     case VR_INTEGRATOR_NANOVDB_EMISSION:                 return cast_ray_grid_marcher(d, 1);
+    case VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE:       return cast_ray_marcher(d, 2); /* same castRay walk (:12-60, :155-168) */
     default:                                             return cast_ray_delta(d);
     }
 }
@@ -1264,7 +1326,8 @@ static v3 cast_ray(path_ctx* d, int integrator)
 static int scene_ok(const vro_scene* sc, int integrator)
 {
     if (integrator < 0 || integrator >= VR_INTEGRATOR_COUNT) return VR_ERR_INVALID_ARG;
-    if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
+    if (integrator == VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE) { if (!sc->mesh) return VR_ERR_NO_MESH; }
+    else if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
         if (!sc->density) return VR_ERR_NO_DENSITY;
         if (integrator == VR_INTEGRATOR_NANOVDB_EMISSION && !sc->temperature) return VR_ERR_NO_DENSITY; /* Emission :13-18 exits */
     }

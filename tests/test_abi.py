@@ -62,6 +62,7 @@ def test_unknown_integrator_name_raises():
         backend.integrator_id("densitySampling")   # known to the reference's factory, not on this path
     assert backend.integrator_id("deltaTracking") == 3
     assert backend.integrator_id("nanoVDBSimple") == 4 and backend.integrator_id("nanoVDBEmission") == 5
+    assert backend.integrator_id("heterogeneousPerlinNoise") == 6
 
 
 def test_rgb_to_u8_matches_oracle_savefile_conversion(oracle):

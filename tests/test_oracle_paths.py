@@ -272,3 +272,23 @@ def test_grid_marcher_transmittance_and_emission_on_a_homogeneous_box(oracle):
     T = np.cumprod(np.full(steps, math.exp(-0.5 * sig)))
     want_e = bg * T[-1] + np.array([1.0, 0.5, 0.25]) * (0.01 * 4.0) * 0.5 * T.sum()
     assert np.allclose(e, want_e, rtol=1e-4), (e, want_e)
+
+
+def test_perlin_marcher_attenuates_by_the_noise_density(oracle):
+    """heterogeneousPerlinNoise with a black light: background * prod exp(-0.2 * rho(sample) * sigma_t) along
+    the chord, rho = eval_density in [0, 1]; so the pixel lies between the homogeneous rho = 1 and rho = 0 cases
+    and equals the product over the Philox-jittered sample positions."""
+    mesh = scenes.cube_mesh(side=4.0, center=(0, 0, 0))
+    sc, _ = ol.make_scene(mesh=mesh)
+    o = scenes.options_marcher(9, 9, 1, cameraPosition=(0.0, 0.0, 10.0), fov=10.0, lightColor=(0.0, 0.0, 0.0),
+                               sigma_a=0.3, sigma_s=0.4)
+    img, st = ol.render(sc, o, 6, want_stats=True)
+    bg = np.array(o.backgroundColor[:], dtype=f32)
+    T = img[4, 4] / bg
+    assert np.allclose(T, T[0], rtol=1e-6)
+    ns = math.ceil((4.0 - 0.001) / 0.2)
+    assert math.exp(-0.2 * 0.7 * ns) < T[0] < 1.0
+    pts = np.array([[0.3, -1.2, 0.7], [10.5, 2.25, -3.0], [0.0, 0.0, 0.0]], dtype=f32)
+    rho = [oracle.vro_perlin_eval_density(ol.fptr(np.ascontiguousarray(q))) for q in pts]
+    assert all(0.0 <= r <= 1.0 for r in rho) and rho[2] == 0.5
+    assert st["density_lookups"] >= 81 * 0 + ns and st["path_samples"] == 81

@@ -15,6 +15,7 @@ INTEGRATORS = {
     "deltaTracking": 3,
     "nanoVDBSimple": 4,
     "nanoVDBEmission": 5,
+    "heterogeneousPerlinNoise": 6,
 }
 
 VR_OK = 0

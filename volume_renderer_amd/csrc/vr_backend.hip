@@ -123,43 +123,6 @@ __global__ void __launch_bounds__(256) k_skip_make(const float* __restrict__ bri
     }
 }
 
-// Ken Perlin's reference permutation — the table of Utils/PerlinNoiseSampler.cpp:11-28 (data)
-__constant__ uint8_t c_perm[256] = {
-    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142, 8,   99,
-    37,  240, 21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203, 117, 35,  11,  32,
-    57,  177, 33,  88,  237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165, 71,  134, 139, 48,  27,  166,
-    77,  146, 158, 231, 83,  111, 229, 122, 60,  211, 133, 230, 220, 105, 92,  41,  55,  46,  245, 40,  244, 102, 143, 54,
-    65,  25,  63,  161, 1,   216, 80,  73,  209, 76,  132, 187, 208, 89,  18,  169, 200, 196, 135, 130, 116, 188, 159, 86,
-    164, 100, 109, 198, 173, 186, 3,   64,  52,  217, 226, 250, 124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212,
-    207, 206, 59,  227, 47,  16,  58,  17,  182, 189, 28,  42,  223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,
-    221, 153, 101, 155, 167, 43,  172, 9,   129, 22,  39,  253, 19,  98,  108, 110, 79,  113, 224, 232, 178, 185, 112, 104,
-    218, 246, 97,  228, 251, 34,  242, 193, 238, 210, 144, 12,  191, 179, 162, 241, 81,  51,  145, 235, 249, 14,  239, 107,
-    49,  192, 214, 31,  181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,   150, 254, 138, 236, 205, 93,
-    222, 114, 67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180
-};
-__device__ __forceinline__ int pp(int i) { return c_perm[i & 255]; }
-__device__ __forceinline__ float pn_fade(float t) { return t * t * t * (t * (t * 6 - 15) + 10); }        // :32
-__device__ __forceinline__ float pn_lerp(float t, float a, float b) { return a + t * (b - a); }            // :33
-__device__ __forceinline__ float pn_grad(int hash, float x, float y, float z)                              // :34-40
-{
-    int   h = hash & 15;
-    float u = h < 8 ? x : y;
-    float v = h < 4 ? y : (h == 12 || h == 14) ? x : z;
-    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
-}
-__device__ float perlin_noise(float x, float y, float z)                                                   // :46-68
-{
-    int X = (int)floorf(x) & 255, Y = (int)floorf(y) & 255, Z = (int)floorf(z) & 255;
-    x -= floorf(x); y -= floorf(y); z -= floorf(z);
-    float u = pn_fade(x), v = pn_fade(y), w = pn_fade(z);
-    int A = pp(X) + Y, AA = pp(A) + Z, AB = pp(A + 1) + Z;
-    int B = pp(X + 1) + Y, BA = pp(B) + Z, BB = pp(B + 1) + Z;
-    return pn_lerp(w,
-        pn_lerp(v, pn_lerp(u, pn_grad(pp(AA), x, y, z), pn_grad(pp(BA), x - 1, y, z)),
-                   pn_lerp(u, pn_grad(pp(AB), x, y - 1, z), pn_grad(pp(BB), x - 1, y - 1, z))),
-        pn_lerp(v, pn_lerp(u, pn_grad(pp(AA + 1), x, y, z - 1), pn_grad(pp(BA + 1), x - 1, y, z - 1)),
-                   pn_lerp(u, pn_grad(pp(AB + 1), x, y - 1, z - 1), pn_grad(pp(BB + 1), x - 1, y - 1, z - 1))));
-}
 // the synthetic cloud of BASELINE configs 2-4, written straight into brick order
 // (same expression sequence as the oracle's cloud_density)
 __global__ void __launch_bounds__(256) k_cloud(float* __restrict__ bricks, int n, int nb, float R)
@@ -182,7 +145,7 @@ __global__ void __launch_bounds__(256) k_cloud(float* __restrict__ bricks, int n
         if (fall > 0.0f) {
             float f = 4.0f / (float)n, amp = 1.0f, sum = 0.0f;
             for (int oc = 0; oc < 4; ++oc) {
-                sum = sum + amp * perlin_noise(px * f + 17.0f, py * f + 17.0f, pz * f + 17.0f);
+                sum = sum + amp * vr::perlin_noise(px * f + 17.0f, py * f + 17.0f, pz * f + 17.0f);
                 f = f * 2.0f;
                 amp = amp * 0.5f;
             }
@@ -533,7 +496,7 @@ int validate(vr_backend* b, const vr_options_pod* o, int integrator)
         if (!b->has_density) return fail(b, VR_ERR_NO_DENSITY, "the grid marchers need a density grid (SceneLoader.cpp:212-213)");
         if (integrator == VR_INTEGRATOR_NANOVDB_EMISSION && !b->has_temperature)
             return fail(b, VR_ERR_NO_DENSITY, "nanoVDBEmission needs a temperature grid (IntegratorNanoVDBEmission.cpp:13-18 exits)");
-    } else if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
+    } else if (integrator == VR_INTEGRATOR_RATIO_TRACKING || integrator == VR_INTEGRATOR_DELTA_TRACKING) {
         if (!b->has_density) return fail(b, VR_ERR_NO_DENSITY, "tracking integrators need a density grid (SceneLoader.cpp:212-213)");
         // every step must advance t in float, or the reference's loops never end
         if (!(o->stepSizeMin > 0.0f) || !(o->stepSizeMax >= o->stepSizeMin))
@@ -712,8 +675,10 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             p.max_depth = o->maxDepth;
             void (*kern)(const MarchParams) =
                 integrator == VR_INTEGRATOR_HOMOGENEOUS_RAY_MARCHER_NEE
-                    ? (exact ? vr_march_kernel<false, true> : vr_march_kernel<false, false>)
-                    : (exact ? vr_march_kernel<true, true> : vr_march_kernel<true, false>);
+                    ? (exact ? vr_march_kernel<MARCH_NEE, true> : vr_march_kernel<MARCH_NEE, false>)
+                : integrator == VR_INTEGRATOR_HOMOGENEOUS_RAY_MARCHER_IMPROVED
+                    ? (exact ? vr_march_kernel<MARCH_IMPROVED, true> : vr_march_kernel<MARCH_IMPROVED, false>)
+                    : (exact ? vr_march_kernel<MARCH_PERLIN, true> : vr_march_kernel<MARCH_PERLIN, false>);
             const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(8ull * b->num_cu, (work.nitems + 255ull) / 256));
             HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);

@@ -247,6 +247,51 @@ __device__ __forceinline__ float grid_value_nocache(const GridDev& g, f3 p)
     return g.bricks[brick_offset(g, (uint32_t)i, (uint32_t)j, (uint32_t)k)];
 }
 
+// ---- Perlin noise (Utils/PerlinNoiseSampler.cpp) --------------------------------------------------
+// Ken Perlin's reference permutation — the table of Utils/PerlinNoiseSampler.cpp:11-28 (data)
+__constant__ uint8_t c_perm[256] = {
+    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142, 8,   99,
+    37,  240, 21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203, 117, 35,  11,  32,
+    57,  177, 33,  88,  237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165, 71,  134, 139, 48,  27,  166,
+    77,  146, 158, 231, 83,  111, 229, 122, 60,  211, 133, 230, 220, 105, 92,  41,  55,  46,  245, 40,  244, 102, 143, 54,
+    65,  25,  63,  161, 1,   216, 80,  73,  209, 76,  132, 187, 208, 89,  18,  169, 200, 196, 135, 130, 116, 188, 159, 86,
+    164, 100, 109, 198, 173, 186, 3,   64,  52,  217, 226, 250, 124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212,
+    207, 206, 59,  227, 47,  16,  58,  17,  182, 189, 28,  42,  223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,
+    221, 153, 101, 155, 167, 43,  172, 9,   129, 22,  39,  253, 19,  98,  108, 110, 79,  113, 224, 232, 178, 185, 112, 104,
+    218, 246, 97,  228, 251, 34,  242, 193, 238, 210, 144, 12,  191, 179, 162, 241, 81,  51,  145, 235, 249, 14,  239, 107,
+    49,  192, 214, 31,  181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,   150, 254, 138, 236, 205, 93,
+    222, 114, 67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180
+};
+__device__ __forceinline__ int pp(int i) { return c_perm[i & 255]; }
+__device__ __forceinline__ float pn_fade(float t) { return t * t * t * (t * (t * 6 - 15) + 10); }        // :32
+__device__ __forceinline__ float pn_lerp(float t, float a, float b) { return a + t * (b - a); }            // :33
+__device__ __forceinline__ float pn_grad(int hash, float x, float y, float z)                              // :34-40
+{
+    int   h = hash & 15;
+    float u = h < 8 ? x : y;
+    float v = h < 4 ? y : (h == 12 || h == 14) ? x : z;
+    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+}
+__device__ __forceinline__ float perlin_noise(float x, float y, float z)                                                   // :46-68
+{
+    int X = (int)floorf(x) & 255, Y = (int)floorf(y) & 255, Z = (int)floorf(z) & 255;
+    x -= floorf(x); y -= floorf(y); z -= floorf(z);
+    float u = pn_fade(x), v = pn_fade(y), w = pn_fade(z);
+    int A = pp(X) + Y, AA = pp(A) + Z, AB = pp(A + 1) + Z;
+    int B = pp(X + 1) + Y, BA = pp(B) + Z, BB = pp(B + 1) + Z;
+    return pn_lerp(w,
+        pn_lerp(v, pn_lerp(u, pn_grad(pp(AA), x, y, z), pn_grad(pp(BA), x - 1, y, z)),
+                   pn_lerp(u, pn_grad(pp(AB), x, y - 1, z), pn_grad(pp(BB), x - 1, y - 1, z))),
+        pn_lerp(v, pn_lerp(u, pn_grad(pp(AA + 1), x, y, z - 1), pn_grad(pp(BA + 1), x - 1, y, z - 1)),
+                   pn_lerp(u, pn_grad(pp(AB + 1), x, y - 1, z - 1), pn_grad(pp(BB + 1), x - 1, y - 1, z - 1))));
+}
+// PerlinNoiseSampler::eval_density: noise at frequency 1.8 remapped to [0,1]                  PerlinNoiseSampler.cpp:94-98
+__device__ __forceinline__ float perlin_eval_density(f3 p)
+{
+    const float freq = 1.8f;
+    return (float)((1 + perlin_noise(p.x * freq, p.y * freq, p.z * freq)) * 0.5);
+}
+
 // ---- phase function and direction sampling -----------------------------------------------------
 // PhaseFunction::henyey_greenstein                                                              PhaseFunction.cpp:4-8
 __device__ __forceinline__ float hg_phase(float g, float cos_theta)

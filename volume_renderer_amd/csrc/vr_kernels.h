@@ -670,10 +670,15 @@ __device__ __forceinline__ int closest_hit(const MeshDev& m, f3 org, f3 dir, flo
     return best_prim == 0xffffffffu ? -1 : (int)best_prim;
 }
 
-template <bool IMPROVED, bool EXACT>
+// KIND: which handleIntersection marches the segment between entry and exit hit
+enum { MARCH_NEE = 0, MARCH_IMPROVED = 1, MARCH_PERLIN = 2 };
+
+template <int KIND, bool EXACT>
 __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
 {
     typedef Math<EXACT> M;
+    constexpr bool IMPROVED = KIND == MARCH_IMPROVED;
+    unsigned long long n_lookups = 0;
     const uint32_t k0 = p.work.key0, k1 = p.work.key1;
     uint32_t n_queries = 0, n_light = 0, n_paths = 0;
     for (uint32_t mine = blockIdx.x * blockDim.x + threadIdx.x; mine < p.work.nitems; mine += gridDim.x * blockDim.x) {
@@ -705,7 +710,58 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
             const f3 hit_point = add3(scale3(dir, tfar), origin);               // :34
             const float dissolve = p.mesh.shape_dissolve[object_id];            // :49
             if (dissolve > 0) {                                                 // :52
-                if (previous_id == object_id) {                                 // :55 exit hit: march the segment
+                if (KIND == MARCH_PERLIN && previous_id == object_id) {
+                    // IntegratorHeterogeneousPerlinNoise::handleIntersection (IntegratorHeterogeneousPerlinNoise.cpp:62-153):
+                    // density from PerlinNoiseSampler::eval_density at every sample and along every light ray;
+                    // the step is NOT rescaled to distance / ns here
+                    float       transparency = 1;
+                    f3          acc = mk3(0, 0, 0);
+                    const float distance = tfar;                                // :64
+                    const f3    light_dir = mk3(p.light[0], p.light[1], p.light[2]);
+                    const f3    light_color = mk3(p.light_color[0], p.light_color[1], p.light_color[2]);
+                    const float sigma_t = p.sigma_a + p.sigma_s;                // :74
+                    const float step_size = 0.2f;                               // :78
+                    const int   ns = (int)ceilf(distance / step_size);          // :79
+                    const f3    nd = normalize3(dir);                           // :86
+                    for (int n = 0; n < ns; n++) {                              // :89
+                        uint32_t w0, w1, w2, w3;   // one Philox block per march step: jitter, roulette
+                        philox4x32_10(rng_pixel, s, 0u, (uint32_t)n, k0, k1, w0, w1, w2, w3);
+                        const float tt = (float)(step_size * ((double)n + (double)unit24(w0)));   // :91-99
+                        const f3    sp = add3(origin, scale3(nd, tt));          // :101
+                        const float density = perlin_eval_density(sp);          // :103
+                        n_lookups++;
+                        transparency *= M::exp_(-step_size * density * sigma_t);   // :106-109
+                        const f3 lo = add3(sp, scale3(light_dir, 0.001f));      // :112-113
+                        float    dl = 0;
+                        bool     lit = false;
+                        if (density > 0) { n_queries++; n_light++; lit = closest_hit(p.mesh, lo, light_dir, dl) >= 0; }   // :116-117
+                        if (lit) {
+                            float       tau = 0;
+                            const float num_steps_light = ceilf(dl / step_size);   // :120
+                            for (uint32_t nl = 0; (float)nl < num_steps_light; ++nl) {   // :122
+                                const float t_light = (float)(step_size * ((double)nl + 0.5));   // :123
+                                tau += perlin_eval_density(add3(sp, scale3(light_dir, t_light)));   // :124-125
+                                n_lookups++;
+                            }
+                            const float cos_theta = dot3(nd, light_dir);        // :128
+                            const float la = M::exp_(-tau * step_size * sigma_t);   // :129
+                            f3 c = scale3(light_color, la);                     // :130-137
+                            c = scale3(c, density);
+                            c = scale3(c, p.sigma_s);
+                            c = scale3(c, hg_phase(p.g, cos_theta));
+                            c = scale3(c, transparency);
+                            c = scale3(c, step_size);
+                            acc = add3(acc, c);
+                            if ((double)transparency < 1e-3) {                  // :140-148
+                                if (in_range(w1, 0, 1) > 1.f / 2) n = ns;
+                                else transparency *= 2;
+                            }
+                        }
+                    }
+                    result = add3(scale3(bg, transparency), acc);               // :153
+                    break;
+                }
+                if (KIND != MARCH_PERLIN && previous_id == object_id) {         // :55 exit hit: march the segment
                     float       transparency = 1;
                     f3          acc = mk3(0, 0, 0);
                     const float distance = tfar;                                // :59
@@ -775,11 +831,12 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
         }
         store_sample(p.work.samples, mine, result);
     }
-    unsigned long long a = wave_sum(n_paths), b = wave_sum(n_queries), c = wave_sum(n_light);
+    unsigned long long a = wave_sum(n_paths), b = wave_sum(n_queries), c = wave_sum(n_light), e = wave_sum(n_lookups);
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&p.work.counters->path_samples, a);
         atomicAdd(&p.work.counters->ray_queries, b);
         atomicAdd(&p.work.counters->shadow_rays, c);
+        if (KIND == MARCH_PERLIN) atomicAdd(&p.work.counters->density_lookups, e);
     }
 }
 

@@ -106,6 +106,7 @@ struct IntegratorFactory {
             { "deltaTracking", VR_INTEGRATOR_DELTA_TRACKING },
             { "nanoVDBSimple", VR_INTEGRATOR_NANOVDB_SIMPLE },
             { "nanoVDBEmission", VR_INTEGRATOR_NANOVDB_EMISSION },
+            { "heterogeneousPerlinNoise", VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE },
         };
         for (const auto& e : table)
             if (name == e.name) return std::make_unique<BaseIntegrator>(e.id);
