@@ -25,7 +25,8 @@ typedef enum vr_integrator_id {
     VR_INTEGRATOR_NANOVDB_SIMPLE                   = 4, /* "nanoVDBSimple"                 */
     VR_INTEGRATOR_NANOVDB_EMISSION                 = 5, /* "nanoVDBEmission"               */
     VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE       = 6, /* "heterogeneousPerlinNoise"      */
-    VR_INTEGRATOR_COUNT                            = 7
+    VR_INTEGRATOR_DENSITY_SAMPLING                 = 7, /* "densitySampling"               */
+    VR_INTEGRATOR_COUNT                            = 8
 } vr_integrator_id;
 
 /* POD mirror of `struct Options` (Utils/Types.h:85-122) without the strings/vectors.
@@ -101,6 +102,8 @@ typedef struct vr_mesh_desc {
     uint32_t        ntris;
     const uint32_t* prim_to_shape;  /* ntris */
     const float*    shape_dissolve; /* nshapes */
+    const float*    shape_diffuse;  /* nshapes * 3: materials[...].diffuse (IntegratorDensitySampling.cpp:54);
+                                       NULL = black; only densitySampling reads it */
     uint32_t        nshapes;
 } vr_mesh_desc;
 

@@ -203,7 +203,7 @@ long long refk_bridge_grid(void* h, int* bmin, int* bmax, float* inv_mat9, float
 /* tinyobj::LoadObj as SceneLoader.cpp:79 calls it, then describeMesh; counts[3] = nverts, ntris, nshapes;
  * arrays may be NULL to query the counts first.  Returns 0 on success. */
 int refk_bridge_obj(const char* obj_path, const char* base_dir, unsigned* counts, float* verts, unsigned* tri_idx,
-                    unsigned* prim_to_shape, float* dissolve)
+                    unsigned* prim_to_shape, float* dissolve, float* diffuse)
 {
     tinyobj::attrib_t attrib;
     std::vector<tinyobj::shape_t> shapes;
@@ -217,6 +217,7 @@ int refk_bridge_obj(const char* obj_path, const char* base_dir, unsigned* counts
     if (tri_idx) memcpy(tri_idx, soup.tri_idx.data(), soup.tri_idx.size() * sizeof(unsigned));
     if (prim_to_shape) memcpy(prim_to_shape, soup.prim_to_shape.data(), soup.prim_to_shape.size() * sizeof(unsigned));
     if (dissolve) memcpy(dissolve, soup.shape_dissolve.data(), soup.shape_dissolve.size() * sizeof(float));
+    if (diffuse) memcpy(diffuse, soup.shape_diffuse.data(), soup.shape_diffuse.size() * sizeof(float));
     return 0;
 }
 

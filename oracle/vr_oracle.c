@@ -1196,6 +1196,28 @@ static v3 march_segment_perlin(path_ctx* d)
     return v3_add(v3_scale(opt3(o->backgroundColor), transparency), result); /* :153 */
 }
 
+/* IntegratorDensitySampling (REF integrators/IntegratorDensitySampling.cpp:7-78): analytic Beer-Lambert
+ * between entry and exit hit of ANY object (no dissolve test), tinted by the material's diffuse colour. */
+static v3 cast_ray_density_sampling(path_ctx* d)
+{
+    const vr_options_pod* o = d->o;
+    const vr_mesh_desc* m = d->sc->mesh;
+    for (int guard = 0; guard < 4096; ++guard) {
+        if (0 >= o->maxDepth) return v3_make(0, 0, 0);                      /* :9-11 (depth stays 0) */
+        if (!cast_single_ray(d)) return opt3(o->backgroundColor);          /* :13-42 */
+        if (d->previousObjectId == d->objectId) {                           /* :50 exit intersection */
+            float distance = d->tFar;
+            float sigma_a = o->sigma_a;
+            const float* df = m->shape_diffuse ? m->shape_diffuse + 3 * (size_t)d->objectId : NULL;
+            v3 scatteringColor = df ? v3_make(df[0], df[1], df[2]) : v3_make(0, 0, 0); /* :54 */
+            float transmission = m_expf(-distance * sigma_a);               /* :55 */
+            return v3_add(v3_scale(opt3(o->backgroundColor), transmission), v3_scale(scatteringColor, 1 - transmission)); /* :57 */
+        }
+        d->rayOrigin = v3_add(d->hitPoint, v3_scale(d->rayDirection, 0.001f)); /* :62 */
+    }
+    return v3_make(0, 0, 0);
+}
+
 /* castRay + handleIntersection unrolled into a loop
  * (REF IntegratorHomogeneousRayMarcherNEE.cpp:10-118; Improved :11-149 is the same walk). */
 static v3 cast_ray_marcher(path_ctx* d, int improved)
@@ -1319,6 +1341,7 @@ static v3 cast_ray(path_ctx* d, int integrator)
     case VR_INTEGRATOR_NANOVDB_SIMPLE:                   return cast_ray_grid_marcher(d, 0);
     case VR_INTEGRATOR_NANOVDB_EMISSION:                 return cast_ray_grid_marcher(d, 1);
     case VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE:       return cast_ray_marcher(d, 2); /* same castRay walk (:12-60, :155-168) */
+    case VR_INTEGRATOR_DENSITY_SAMPLING:                 return cast_ray_density_sampling(d);
     default:                                             return cast_ray_delta(d);
     }
 }
@@ -1326,7 +1349,7 @@ static v3 cast_ray(path_ctx* d, int integrator)
 static int scene_ok(const vro_scene* sc, int integrator)
 {
     if (integrator < 0 || integrator >= VR_INTEGRATOR_COUNT) return VR_ERR_INVALID_ARG;
-    if (integrator == VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE) { if (!sc->mesh) return VR_ERR_NO_MESH; }
+    if (integrator == VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE || integrator == VR_INTEGRATOR_DENSITY_SAMPLING) { if (!sc->mesh) return VR_ERR_NO_MESH; }
     else if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
         if (!sc->density) return VR_ERR_NO_DENSITY;
         if (integrator == VR_INTEGRATOR_NANOVDB_EMISSION && !sc->temperature) return VR_ERR_NO_DENSITY; /* Emission :13-18 exits */

@@ -59,7 +59,8 @@ def test_create_without_gpu_returns_an_error_code():
 def test_unknown_integrator_name_raises():
     import pytest
     with pytest.raises(ValueError):
-        backend.integrator_id("densitySampling")   # known to the reference's factory, not on this path
+        backend.integrator_id("pathTracing")        # not a name of the reference's factory
+    assert backend.integrator_id("densitySampling") == 7
     assert backend.integrator_id("deltaTracking") == 3
     assert backend.integrator_id("nanoVDBSimple") == 4 and backend.integrator_id("nanoVDBEmission") == 5
     assert backend.integrator_id("heterogeneousPerlinNoise") == 6

@@ -14,7 +14,7 @@ from volume_renderer_amd import MODE_EXACT, MODE_EXACT_SKIP, MODE_FAST, Backend,
 
 pytestmark = pytest.mark.gpu
 
-RATIO, DELTA, NEE, IMPROVED, VDB_SIMPLE, VDB_EMISSION, PERLIN = 2, 3, 0, 1, 4, 5, 6
+RATIO, DELTA, NEE, IMPROVED, VDB_SIMPLE, VDB_EMISSION, PERLIN, DENSITY = 2, 3, 0, 1, 4, 5, 6, 7
 
 
 @pytest.fixture(scope="module")
@@ -276,6 +276,30 @@ def test_marcher_fast_mode_within_1e4(backend, oracle):
     got = backend.render(o, NEE)
     rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-6)
     assert rel.max() < 1e-4, rel.max()
+
+
+def test_density_sampling_exact_and_fast(backend, oracle):
+    """densitySampling (analytic Beer-Lambert, per-shape diffuse tint): exact mode bit-identical, fast <= 1e-4."""
+    base = scenes.two_object_mesh()
+    from volume_renderer_amd.abi import Mesh
+    mesh = Mesh(base.verts, base.tris, base.prim_to_shape, base.shape_dissolve, shape_diffuse=[[0.9, 0.3, 0.1], [0.1, 0.4, 0.8]])
+    o = scenes.options_marcher(80, 72, 4, sigma_a=0.45)
+    sc, _ = ol.make_scene(mesh=mesh)
+    want, wst = oracle_image(oracle, sc, o, DENSITY)
+    backend.set_mesh(mesh)
+    backend.set_mode(MODE_EXACT)
+    got = backend.render(o, DENSITY)
+    assert bitexact(got, want) and backend.last_stats()["ray_queries"] == wst["ray_queries"]
+    assert len(np.unique(want.reshape(-1, 3), axis=0)) > 50          # two tinted media over the sky
+    backend.set_mode(MODE_FAST)
+    oracle.vro_set_math_mode(ol.MATH_LIBM)
+    libm = ol.render(sc, o, DENSITY)
+    rel = np.abs(backend.render(o, DENSITY) - libm) / np.maximum(np.abs(libm), 1e-6)
+    assert rel.max() < 1e-4, rel.max()
+    backend.set_mesh(base)                                            # no diffuse table: black tint
+    sc0, _ = ol.make_scene(mesh=base)
+    backend.set_mode(MODE_EXACT)
+    assert bitexact(backend.render(o, DENSITY), oracle_image(oracle, sc0, o, DENSITY)[0])
 
 
 def test_perlin_marcher_fast_mode(backend, oracle):

@@ -43,7 +43,7 @@ def ref():
     L.refk_bridge_grid.argtypes = [C.c_void_p, pi, pi, pf, pf, pf, pf, C.c_longlong, pf]
     L.refk_grid_mat.argtypes = [C.c_void_p, pf]
     L.refk_index_to_world.argtypes = [C.c_void_p, pf, C.c_int, pf]
-    L.refk_bridge_obj.argtypes = [C.c_char_p, C.c_char_p, pu, pf, pu, pu, pf]
+    L.refk_bridge_obj.argtypes = [C.c_char_p, C.c_char_p, pu, pf, pu, pu, pf, pf]
     return L
 
 
@@ -109,18 +109,18 @@ def _load_obj(ref, name):
     if not os.path.exists(path):
         pytest.skip("reference Models/ not present")
     counts = (C.c_uint * 3)()
-    assert ref.refk_bridge_obj(path.encode(), MODELS.encode(), counts, None, None, None, None) == 0
+    assert ref.refk_bridge_obj(path.encode(), MODELS.encode(), counts, None, None, None, None, None) == 0
     nv, nt, ns = counts[0], counts[1], counts[2]
     verts, tris = np.zeros((nv, 3), f32), np.zeros((nt, 3), np.uint32)
-    p2s, dis = np.zeros(nt, np.uint32), np.zeros(ns, f32)
+    p2s, dis, dif = np.zeros(nt, np.uint32), np.zeros(ns, f32), np.zeros((ns, 3), f32)
     assert ref.refk_bridge_obj(path.encode(), MODELS.encode(), counts, fp(verts), tris.ctypes.data_as(pu),
-                               p2s.ctypes.data_as(pu), fp(dis)) == 0
-    return verts, tris, p2s, dis
+                               p2s.ctypes.data_as(pu), fp(dis), fp(dif)) == 0
+    return verts, tris, p2s, dis, dif
 
 
 def test_describe_mesh_on_the_reference_sphere(ref, oracle):
     """SphereOnly.obj: 162 vertices / 320 triangles, one shape; the marcher then sees a medium."""
-    verts, tris, p2s, dis = _load_obj(ref, "SphereOnly.obj")
+    verts, tris, p2s, dis, _dif = _load_obj(ref, "SphereOnly.obj")
     assert verts.shape[0] == 162 and tris.shape[0] == 320
     assert tris.max() == 161 and np.all(p2s == 0) and len(dis) == 1 and dis[0] > 0
     r = np.linalg.norm(verts - verts.mean(axis=0), axis=1)
@@ -138,8 +138,10 @@ def test_describe_mesh_on_the_reference_sphere(ref, oracle):
 def test_describe_mesh_keeps_the_global_primitive_table(ref):
     """CornellBox-Sphere.obj (2192 triangles, several shapes): prim_to_shape is the reference's
     `primitives` table — one entry per face, shape ids non-decreasing in file order."""
-    verts, tris, p2s, dis = _load_obj(ref, "CornellBox-Sphere.obj")
+    verts, tris, p2s, dis, dif = _load_obj(ref, "CornellBox-Sphere.obj")
     assert tris.shape[0] == 2192 and tris.max() < verts.shape[0]
     assert len(dis) == p2s.max() + 1 and len(dis) > 1
     assert np.all(np.diff(p2s.astype(np.int64)) >= 0)
     assert np.all((dis > 0) & (dis <= 1))
+    # per-shape diffuse colours (densitySampling's tint): the Cornell box has a red and a green wall
+    assert dif.shape == (len(dis), 3) and np.all((dif >= 0) & (dif <= 1)) and len(np.unique(dif, axis=0)) >= 3

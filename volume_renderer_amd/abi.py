@@ -16,6 +16,7 @@ INTEGRATORS = {
     "nanoVDBSimple": 4,
     "nanoVDBEmission": 5,
     "heterogeneousPerlinNoise": 6,
+    "densitySampling": 7,
 }
 
 VR_OK = 0
@@ -90,6 +91,7 @@ class MeshDesc(C.Structure):
         ("ntris", C.c_uint32),
         ("prim_to_shape", C.POINTER(C.c_uint32)),
         ("shape_dissolve", C.POINTER(C.c_float)),
+        ("shape_diffuse", C.POINTER(C.c_float)),
         ("nshapes", C.c_uint32),
     ]
 
@@ -196,7 +198,7 @@ class Grid:
 class Mesh:
     """Owns the arrays behind a MeshDesc."""
 
-    def __init__(self, verts, tris, prim_to_shape=None, shape_dissolve=None):
+    def __init__(self, verts, tris, prim_to_shape=None, shape_dissolve=None, shape_diffuse=None):
         self.verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
         self.tris = np.ascontiguousarray(tris, dtype=np.uint32).reshape(-1, 3)
         nt = self.tris.shape[0]
@@ -214,4 +216,8 @@ class Mesh:
         d.prim_to_shape = self.prim_to_shape.ctypes.data_as(C.POINTER(C.c_uint32))
         d.shape_dissolve = self.shape_dissolve.ctypes.data_as(C.POINTER(C.c_float))
         d.nshapes = self.shape_dissolve.shape[0]
+        if shape_diffuse is not None:
+            self.shape_diffuse = np.ascontiguousarray(shape_diffuse, dtype=np.float32).reshape(-1, 3)
+            assert self.shape_diffuse.shape[0] == d.nshapes
+            d.shape_diffuse = self.shape_diffuse.ctypes.data_as(C.POINTER(C.c_float))
         self.desc = d

@@ -225,7 +225,7 @@ struct vr_backend {
 
     // mesh
     bool      has_mesh = false;
-    BvhNode*  d_nodes = nullptr; TriDev* d_tris = nullptr; uint32_t* d_p2s = nullptr; float* d_dissolve = nullptr;
+    BvhNode*  d_nodes = nullptr; TriDev* d_tris = nullptr; uint32_t* d_p2s = nullptr; float* d_dissolve = nullptr; float* d_diffuse = nullptr;
     uint32_t  nnodes = 0, nshapes = 0;
 
     // scratch
@@ -667,7 +667,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             MarchParams p{};
             p.cam = cam; p.work = work;
             p.mesh.nodes = b->d_nodes; p.mesh.tris = b->d_tris; p.mesh.prim_to_shape = b->d_p2s;
-            p.mesh.shape_dissolve = b->d_dissolve; p.mesh.nnodes = b->nnodes;
+            p.mesh.shape_dissolve = b->d_dissolve; p.mesh.shape_diffuse = b->d_diffuse; p.mesh.nnodes = b->nnodes;
             p.sigma_a = o->sigma_a; p.sigma_s = o->sigma_s; p.g = o->heyneyGreensteinG;
             for (int i = 0; i < 3; ++i) {
                 p.light[i] = o->lightPosition[i]; p.light_color[i] = o->lightColor[i]; p.background[i] = o->backgroundColor[i];
@@ -678,7 +678,9 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                     ? (exact ? vr_march_kernel<MARCH_NEE, true> : vr_march_kernel<MARCH_NEE, false>)
                 : integrator == VR_INTEGRATOR_HOMOGENEOUS_RAY_MARCHER_IMPROVED
                     ? (exact ? vr_march_kernel<MARCH_IMPROVED, true> : vr_march_kernel<MARCH_IMPROVED, false>)
-                    : (exact ? vr_march_kernel<MARCH_PERLIN, true> : vr_march_kernel<MARCH_PERLIN, false>);
+                : integrator == VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE
+                    ? (exact ? vr_march_kernel<MARCH_PERLIN, true> : vr_march_kernel<MARCH_PERLIN, false>)
+                    : (exact ? vr_march_kernel<MARCH_DENSITY, true> : vr_march_kernel<MARCH_DENSITY, false>);
             const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(8ull * b->num_cu, (work.nitems + 255ull) / 256));
             HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
@@ -755,7 +757,7 @@ void vr_backend_destroy(vr_backend* b)
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    void* ptrs[] = { b->d_bricks, b->d_skip, b->d_tbricks, b->d_nodes, b->d_tris, b->d_p2s, b->d_dissolve, b->d_samples,
+    void* ptrs[] = { b->d_bricks, b->d_skip, b->d_tbricks, b->d_nodes, b->d_tris, b->d_p2s, b->d_dissolve, b->d_diffuse, b->d_samples,
                      b->d_rows, b->d_offsets, b->d_work, b->d_counters, b->d_maxbits, b->d_cold };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (Pass& p : b->passes) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -900,9 +902,9 @@ int vr_backend_set_mesh(vr_backend* b, const vr_mesh_desc* m)
         for (int a = 0; a < 3; ++a) { tris[k].v0[a] = v0[a]; tris[k].e1[a] = v1[a] - v0[a]; tris[k].e2[a] = v2[a] - v0[a]; }
         tris[k].prim = prim;
     }
-    void* old[] = { b->d_nodes, b->d_tris, b->d_p2s, b->d_dissolve };
+    void* old[] = { b->d_nodes, b->d_tris, b->d_p2s, b->d_dissolve, b->d_diffuse };
     for (void* p : old) if (p) (void)hipFree(p);
-    b->d_nodes = nullptr; b->d_tris = nullptr; b->d_p2s = nullptr; b->d_dissolve = nullptr;
+    b->d_nodes = nullptr; b->d_tris = nullptr; b->d_p2s = nullptr; b->d_dissolve = nullptr; b->d_diffuse = nullptr;
     HIP_TRY(b, hipMalloc((void**)&b->d_nodes, nodes.size() * sizeof(BvhNode)));
     HIP_TRY(b, hipMalloc((void**)&b->d_tris, tris.size() * sizeof(TriDev)));
     HIP_TRY(b, hipMalloc((void**)&b->d_p2s, (size_t)m->ntris * sizeof(uint32_t)));
@@ -911,6 +913,10 @@ int vr_backend_set_mesh(vr_backend* b, const vr_mesh_desc* m)
     HIP_TRY(b, hipMemcpy(b->d_tris, tris.data(), tris.size() * sizeof(TriDev), hipMemcpyHostToDevice));
     HIP_TRY(b, hipMemcpy(b->d_p2s, m->prim_to_shape, (size_t)m->ntris * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(b, hipMemcpy(b->d_dissolve, m->shape_dissolve, (size_t)m->nshapes * sizeof(float), hipMemcpyHostToDevice));
+    if (m->shape_diffuse) {
+        HIP_TRY(b, hipMalloc((void**)&b->d_diffuse, (size_t)m->nshapes * 3 * sizeof(float)));
+        HIP_TRY(b, hipMemcpy(b->d_diffuse, m->shape_diffuse, (size_t)m->nshapes * 3 * sizeof(float), hipMemcpyHostToDevice));
+    }
     b->nnodes = (uint32_t)nodes.size(); b->nshapes = m->nshapes;
     b->has_mesh = true;
     return VR_OK;

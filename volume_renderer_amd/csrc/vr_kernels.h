@@ -603,6 +603,7 @@ struct MeshDev {
     const TriDev*   tris;
     const uint32_t* prim_to_shape;
     const float*    shape_dissolve;
+    const float*    shape_diffuse;    // nshapes * 3 or nullptr
     uint32_t        nnodes;
 };
 struct MarchParams {
@@ -671,7 +672,7 @@ __device__ __forceinline__ int closest_hit(const MeshDev& m, f3 org, f3 dir, flo
 }
 
 // KIND: which handleIntersection marches the segment between entry and exit hit
-enum { MARCH_NEE = 0, MARCH_IMPROVED = 1, MARCH_PERLIN = 2 };
+enum { MARCH_NEE = 0, MARCH_IMPROVED = 1, MARCH_PERLIN = 2, MARCH_DENSITY = 3 };
 
 template <int KIND, bool EXACT>
 __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
@@ -708,6 +709,20 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
             previous_id = object_id;                                            // :30
             object_id = (int)p.mesh.prim_to_shape[prim];                        // :33
             const f3 hit_point = add3(scale3(dir, tfar), origin);               // :34
+            if (KIND == MARCH_DENSITY) {
+                // IntegratorDensitySampling::handleIntersection (IntegratorDensitySampling.cpp:46-65): analytic
+                // Beer-Lambert between the entry and exit hit of any object, tinted by its diffuse colour
+                if (previous_id == object_id) {
+                    const float transmission = M::exp_(-tfar * p.sigma_a);     // :55
+                    f3 colour = mk3(0, 0, 0);
+                    if (p.mesh.shape_diffuse) colour = mk3(p.mesh.shape_diffuse[3 * object_id], p.mesh.shape_diffuse[3 * object_id + 1],
+                                                           p.mesh.shape_diffuse[3 * object_id + 2]);
+                    result = add3(scale3(bg, transmission), scale3(colour, 1 - transmission));   // :57
+                    break;
+                }
+                origin = add3(hit_point, scale3(dir, 0.001f));                  // :62
+                continue;
+            }
             const float dissolve = p.mesh.shape_dissolve[object_id];            // :49
             if (dissolve > 0) {                                                 // :52
                 if (KIND == MARCH_PERLIN && previous_id == object_id) {

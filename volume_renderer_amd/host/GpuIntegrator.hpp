@@ -107,6 +107,7 @@ struct IntegratorFactory {
             { "nanoVDBSimple", VR_INTEGRATOR_NANOVDB_SIMPLE },
             { "nanoVDBEmission", VR_INTEGRATOR_NANOVDB_EMISSION },
             { "heterogeneousPerlinNoise", VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE },
+            { "densitySampling", VR_INTEGRATOR_DENSITY_SAMPLING },
         };
         for (const auto& e : table)
             if (name == e.name) return std::make_unique<BaseIntegrator>(e.id);

@@ -62,7 +62,7 @@ inline void describeGrid(const GridT& grid, const BBoxT& bbox, float max_value, 
 struct TriangleSoup {
     std::vector<float>    verts;
     std::vector<uint32_t> tri_idx, prim_to_shape;
-    std::vector<float>    shape_dissolve;
+    std::vector<float>    shape_dissolve, shape_diffuse;
     vr_mesh_desc          desc{};
 };
 
@@ -77,7 +77,7 @@ template <typename AttribT, typename ShapesT, typename MaterialsT>
 inline void describeMesh(const AttribT& attrib, const ShapesT& shapes, const MaterialsT& materials, TriangleSoup& out)
 {
     out.verts.assign(attrib.vertices.begin(), attrib.vertices.end());
-    out.tri_idx.clear(); out.prim_to_shape.clear(); out.shape_dissolve.clear();
+    out.tri_idx.clear(); out.prim_to_shape.clear(); out.shape_dissolve.clear(); out.shape_diffuse.clear();
     uint32_t s = 0;
     for (const auto& shape : shapes) {
         const auto& mesh = shape.mesh;
@@ -86,7 +86,9 @@ inline void describeMesh(const AttribT& attrib, const ShapesT& shapes, const Mat
             out.prim_to_shape.push_back(s);
         }
         const int mat = mesh.material_ids.empty() ? -1 : mesh.material_ids[0];
-        out.shape_dissolve.push_back(mat >= 0 && (size_t)mat < materials.size() ? (float)materials[(size_t)mat].dissolve : 1.0f);
+        const bool has_mat = mat >= 0 && (size_t)mat < materials.size();
+        out.shape_dissolve.push_back(has_mat ? (float)materials[(size_t)mat].dissolve : 1.0f);
+        for (int c = 0; c < 3; ++c) out.shape_diffuse.push_back(has_mat ? (float)materials[(size_t)mat].diffuse[c] : 0.0f);
         ++s;
     }
     out.desc.verts_xyz = out.verts.data();
@@ -95,6 +97,7 @@ inline void describeMesh(const AttribT& attrib, const ShapesT& shapes, const Mat
     out.desc.ntris = (uint32_t)(out.tri_idx.size() / 3);
     out.desc.prim_to_shape = out.prim_to_shape.data();
     out.desc.shape_dissolve = out.shape_dissolve.data();
+    out.desc.shape_diffuse = out.shape_diffuse.data();
     out.desc.nshapes = (uint32_t)out.shape_dissolve.size();
 }
 
