@@ -22,6 +22,7 @@ int main()
     g.voxels = vox.data();
     for (int a = 0; a < 3; ++a) { g.bbox_min[a] = -n / 2; g.bbox_max[a] = n / 2 - 1; }
     g.inv_mat[0] = g.inv_mat[4] = g.inv_mat[8] = 1.f;
+    g.mat[0] = g.mat[4] = g.mat[8] = 1.f;
     g.max_value = -1.f;
 
     try {
