@@ -370,6 +370,76 @@ def test_grid_marcher_errors(backend, cloud64):
     assert backend.render(o, VDB_SIMPLE).shape == (8, 8, 3)
 
 
+@pytest.mark.parametrize("RATIO", [2, 3], ids=["config2_ratio", "config3_delta"])
+def test_full_size_frame_properties(backend, oracle, RATIO):
+    """BASELINE configs 2 and 3 at their full size (1920x1080, 512^3 cloud, shipped step parameters; 4 of the
+    64 / 256 sub-samples to keep the test short): determinism, row-partition invariance, sample-pass invariance,
+    sample count, and three full-width rows bit-identical to the oracle run on the read-back density."""
+    import torch
+    n, W, H, spp = 512, 1920, 1080, 4
+    backend.generate_cloud(n, scenes.cloud_radius(n))
+    backend.set_seed(scenes.SEED)
+    backend.set_mode(MODE_EXACT_SKIP)
+    o = scenes.options_cloud(RATIO, n, W, H, spp)
+    full = backend.render(o, RATIO)
+    st = backend.last_stats()
+    assert st["path_samples"] == W * H * spp and st["step_limit_hits"] == 0
+    assert st["density_lookups"] > 1000 * st["path_samples"]
+    assert np.isfinite(full).all() and full.min() >= 0.0
+    assert bitexact(full, backend.render(o, RATIO))                           # deterministic
+    backend.set_sample_buffer_bytes(W * H * 12 * 3)                           # 3 + 1 samples per pass
+    assert bitexact(full, backend.render(o, RATIO))
+    assert backend.last_stats()["kernel_launches"] == 2
+    backend.set_sample_buffer_bytes(4 << 30)
+    rows_max = (H + 2) // 3
+    dev = torch.zeros((rows_max, W, 3), dtype=torch.float32, device="cuda:0")
+    tiled = np.zeros_like(full)
+    for r in range(3):                                                         # as ranks 0..2 of 3 would
+        cnt = len(range(r, H, 3))
+        backend.render_row_set_device(o, RATIO, r, 3, cnt, dev.data_ptr())
+        backend.synchronize()
+        tiled[r::3] = dev.cpu().numpy()[:cnt]
+    assert bitexact(full, tiled)
+    # the oracle on the same density (read back from HBM), rows through the cloud's core and its rim
+    vox, bmin = backend.read_density()
+    grid = Grid(vox, bbox_min=bmin)
+    sc, _keep = ol.make_scene(density=grid)
+    oracle.vro_set_math_mode(ol.MATH_SHARED)
+    try:
+        for j in (H // 2, H // 3, 40):
+            want, _, _ = ol.render_rows(sc, o, RATIO, j, j + 1, rng_mode=ol.RNG_PHILOX, seed=scenes.SEED)
+            assert bitexact(full[j], want[0]), f"row {j}: {np.count_nonzero(full[j].view(np.uint32) != want[0].view(np.uint32))} channels differ"
+    finally:
+        oracle.vro_set_math_mode(ol.MATH_LIBM)
+    backend.set_mode(MODE_FAST)
+    fast = backend.render(o, RATIO)
+    assert np.allclose(fast.mean(axis=(0, 1)), full.mean(axis=(0, 1)), rtol=2e-3)
+    assert np.mean(np.isclose(fast, full, rtol=1e-4, atol=1e-6).all(axis=2)) > 0.98
+
+
+def test_config4_size_properties(backend):
+    """BASELINE config 4's sizes (3840x2160 frame, 1024^3 cloud = 4 GiB in HBM, delta tracking, textbook
+    regime; 1 of 256 sub-samples): determinism, 8-way row interleave = the single frame, sample count."""
+    import torch
+    n, W, H = 1024, 3840, 2160
+    backend.generate_cloud(n, scenes.cloud_radius(n))
+    assert backend.density_max() > 0.5
+    backend.set_seed(scenes.SEED)
+    backend.set_mode(MODE_FAST)
+    o = scenes.options_cloud(DELTA, n, W, H, 1, regime="textbook")
+    full = backend.render(o, DELTA)
+    assert backend.last_stats()["path_samples"] == W * H
+    assert bitexact(full, backend.render(o, DELTA))
+    dev = torch.zeros((H // 8, W, 3), dtype=torch.float32, device="cuda:0")
+    for r in (0, 5):                                                           # two of the eight ranks
+        backend.render_row_set_device(o, DELTA, r, 8, H // 8, dev.data_ptr())
+        backend.synchronize()
+        assert bitexact(full[r::8], dev.cpu().numpy())
+    medium = np.any(full != np.array(o.backgroundColor[:], dtype=np.float32), axis=2)
+    assert 0.1 < medium.mean() < 0.9
+    backend.generate_cloud(64, scenes.cloud_radius(64))                       # release the 4 GiB pair
+
+
 def test_errors_are_reported_not_thrown(backend, cloud64):
     from volume_renderer_amd import BackendError
     b2 = Backend(0)
