@@ -158,48 +158,12 @@ __device__ __forceinline__ uint32_t brick_offset(const GridDev& g, uint32_t i, u
     uint32_t b = ((i >> 3) * (uint32_t)g.nb[1] + (j >> 3)) * (uint32_t)g.nb[2] + (k >> 3);
     return (b << 9) | ((i & 7u) << 6) | ((j & 7u) << 3) | (k & 7u);
 }
-// One-entry register cache: consecutive steps inside one voxel (sub-voxel step sizes are the
-// reference's shipped regime) cost no memory instruction.
-struct VoxelCache {
-    uint32_t idx;
-    float    val;
-};
-__device__ __forceinline__ float grid_value(const GridDev& g, f3 p, VoxelCache& c)
-{
-    int32_t i = (int32_t)floorf(p.x) - g.min[0];
-    int32_t j = (int32_t)floorf(p.y) - g.min[1];
-    int32_t k = (int32_t)floorf(p.z) - g.min[2];
-    if ((uint32_t)i >= (uint32_t)g.dim[0] || (uint32_t)j >= (uint32_t)g.dim[1] || (uint32_t)k >= (uint32_t)g.dim[2])
-        return g.background;
-    uint32_t off = brick_offset(g, (uint32_t)i, (uint32_t)j, (uint32_t)k);
-    if (off != c.idx) {
-        c.val = g.bricks[off];
-        c.idx = off;
-    }
-    return c.val;
-}
-// same lookup, also reporting the voxel (relative to bbox.min) it fell into
-__device__ __forceinline__ float grid_fetch(const GridDev& g, f3 p, VoxelCache& c, int32_t& i, int32_t& j, int32_t& k,
-                                            bool& inside)
-{
-    i = (int32_t)floorf(p.x) - g.min[0];
-    j = (int32_t)floorf(p.y) - g.min[1];
-    k = (int32_t)floorf(p.z) - g.min[2];
-    inside = (uint32_t)i < (uint32_t)g.dim[0] && (uint32_t)j < (uint32_t)g.dim[1] && (uint32_t)k < (uint32_t)g.dim[2];
-    if (!inside) return g.background;
-    uint32_t off = brick_offset(g, (uint32_t)i, (uint32_t)j, (uint32_t)k);
-    if (off != c.idx) {
-        c.val = g.bricks[off];
-        c.idx = off;
-    }
-    return c.val;
-}
 
 // ---- runs of empty-space steps ---------------------------------------------------------------
 // In a voxel with sigma <= 0 the reference's walks only do `tFar += step` with a constant step and
 // no random draw (IntegratorRatioTracking.cpp:84-96, :251-263; IntegratorDeltaTracking.cpp:70-82).
 // empty_run takes as many of those iterations at once as START inside a box — the current voxel, or
-// its whole 8^3 brick when the brick's majorant says it is empty; the caller passes t_safe =
+// the cube of empty voxels around it that the skip grid reports; the caller passes t_safe =
 // min(exit parameter of the shrunk box, t1) — and returns their number (>= 1).  All but the last
 // also END inside the box (and at t <= t1, so none of them is the walk's last); the last one is an
 // ordinary float addition that may leave it.  t advances exactly as that many sequential float
