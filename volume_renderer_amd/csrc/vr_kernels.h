@@ -188,6 +188,8 @@ vr_track_kernel(const TrackParams p)
     float    cur_val = 0.0f;
     uint32_t cur_off = 0xffffffffu;     // its voxel offset (0xffffffff: outside the bbox)
     float    t_span = 0.0f;             // while t < t_span the walk is provably still inside that voxel
+    // one density lookup per completed step of a walk: the walk's step index is added when the walk
+    // ends (temperature lookups are counted where they happen)
     unsigned long long n_lookups = 0;
     uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0;
     unsigned long long w_trips = 0, w_trip_lanes = 0, w_phases = 0;   // wave-uniform divergence counters
@@ -266,6 +268,7 @@ vr_track_kernel(const TrackParams p)
                 const f3 light = mk3(c->light[0], c->light[1], c->light[2]);
                 n_shadow++;
                 const f3 so = ray_at(eye, dir, t0);                               // :226 (segment START)
+                n_lookups += rng_step;
                 rng_tag |= 0x80000000u; rng_step = 0;
                 float c0 = 1e-5f, c1 = VR_FLT_MAX;
                 if (!ray_clip(so, light, c0, c1, c->bmin, c->bmax1)) {            // :229-232
@@ -310,6 +313,7 @@ vr_track_kernel(const TrackParams p)
                     pdf *= hg_phase(c->g, cos_pdf);
                 }
                 wdir = scattered;                                                         // :178
+                n_lookups += rng_step;
                 rng_tag += 1; rng_step = 0;
                 shadow = false;
                 float c0 = 1e-5f, c1 = VR_FLT_MAX;
@@ -329,6 +333,7 @@ vr_track_kernel(const TrackParams p)
         }
         // (3) finished paths store their sample
         if (st == ST_FINISHED) {
+            n_lookups += rng_step; rng_step = 0;
             if (IS) {
                 // color += rayResults[i] / std::max(0.1f, rayPDFs[i])                     BaseIntegrator.cpp:78
                 const float den = (0.1f < pdf) ? pdf : 0.1f;
@@ -454,7 +459,6 @@ vr_track_kernel(const TrackParams p)
                     len = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(u) * c, tmin, p.t_max);
                 }
                 t += len;                                                                     // :88 / :255
-                n_lookups += 1;
                 rng_step += 1;
                 // the second iteration's voxel.  With sub-voxel steps (use_span) few lanes need one,
                 // yet nearly every wave has such a lane: it sits out the second half instead and
@@ -554,7 +558,6 @@ vr_track_kernel(const TrackParams p)
                 } else {
                     t += len;
                 }
-                n_lookups += krun;
                 rng_step += krun;
                 if (t > t1) st = in_shadow ? ST_SHADOW_DONE : ST_ESCAPED;                     // :91 / :258
             }
