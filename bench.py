@@ -147,6 +147,8 @@ def main():
         be.set_mesh(mesh)                            # BVH resident in HBM before timing
     else:
         opts = scenes.options_cloud(integ, n, W, H, spp, regime=regime)
+        if os.environ.get("VR_BENCH_CAMERA_DIST"):   # developer knob: camera distance in cloud radii (default 2.2)
+            opts.cameraPosition[2] = float(os.environ["VR_BENCH_CAMERA_DIST"]) * scenes.cloud_radius(n)
         be.generate_cloud(n, scenes.cloud_radius(n))     # density resident in HBM before timing
 
     from volume_renderer_amd.scheduler import RowScheduler
