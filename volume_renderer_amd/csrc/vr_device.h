@@ -179,16 +179,13 @@ __device__ __forceinline__ uint32_t empty_run(float& t, float t_safe, float step
     uint32_t k = 0;
     if (t_safe > t && et >= 24u && et < 254u) {
         const float x = step * __uint_as_float((277u - et) << 23); // step / ulp(t), exact
-        const float xf = floorf(x);
-        const float fr = x - xf;
-        if (x >= 1.0f && x < 4194304.0f && fr != 0.5f) {
-            const float qf = fr > 0.5f ? xf + 1.0f : xf;
+        const float qf = rintf(x);                                 // q (a tie is excluded below)
+        if (x >= 1.0f && x < 4194304.0f && fabsf(x - qf) != 0.5f) {
             const float qu = qf * __uint_as_float((et - 23u) << 23);   // q * ulp(t), exact
-            const float rq = __builtin_amdgcn_rcpf(qf);
-            // steps until the box / ray end, and until the mantissa would leave the binade
-            const float k1 = floorf((t_safe - t) * __builtin_amdgcn_rcpf(qu) * 0.999999f) - 1.0f;
-            const float k2 = floorf((float)(0x7fffffu - (tb & 0x7fffffu)) * rq * 0.999999f) - 1.0f;
-            const float kf = fminf(fminf(k1, k2), 65536.0f);
+            // the batched steps stay at or below the last float of t's binade, so the bit pattern
+            // never carries into the exponent, and at or below t_safe
+            const float t_lim = fminf(t_safe, __uint_as_float(tb | 0x7fffffu));
+            const float kf = floorf((t_lim - t) * __builtin_amdgcn_rcpf(qu) * 0.999999f) - 1.0f;
             if (kf >= 1.0f) {
                 k = (uint32_t)kf;
                 t = __uint_as_float(tb + k * (uint32_t)qf);
