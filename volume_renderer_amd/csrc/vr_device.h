@@ -184,7 +184,8 @@ __device__ __forceinline__ uint32_t empty_run(float& t, float t_safe, float step
             const float qu = qf * __uint_as_float((et - 23u) << 23);   // q * ulp(t), exact
             // the batched steps stay at or below the last float of t's binade, so the bit pattern
             // never carries into the exponent, and at or below t_safe
-            const float t_lim = fminf(t_safe, __uint_as_float(tb | 0x7fffffu));
+            const float t_last = __uint_as_float(tb | 0x7fffffu);
+            const float t_lim = t_safe < t_last ? t_safe : t_last;
             const float kf = floorf((t_lim - t) * __builtin_amdgcn_rcpf(qu) * 0.999999f) - 1.0f;
             if (kf >= 1.0f) {
                 k = (uint32_t)kf;

@@ -559,7 +559,7 @@ vr_track_kernel(const TrackParams p)
                     // the skip grid holds -(r + 1) where every voxel of the cube of radius r is empty
                     float t_safe = t_span;
                     if (cur_val < -1.5f) t_safe = cube_span(-1.0f - cur_val);
-                    krun = empty_run(t, fminf(t_safe, t1), len);
+                    krun = empty_run(t, t_safe < t1 ? t_safe : t1, len);   // (no NaNs here: a compare + select, not fminf's canonicalisation)
                 } else {
                     t += len;
                 }
