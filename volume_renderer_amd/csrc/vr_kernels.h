@@ -1,22 +1,24 @@
 // vr_kernels.h — the integrator kernels (gfx950, wave64).
 //
-//   vr_track_kernel<INTEG, EXACT>  ratio tracking / delta tracking through the bricked grid
+//   vr_track_kernel<INTEG, EXACT, SKIP, IS, TEMP, SPAN>
+//                                  ratio tracking / delta tracking through the bricked grid
 //                                  (IntegratorRatioTracking.cpp:11-283, IntegratorDeltaTracking.cpp:11-176)
-//   vr_march_kernel<IMPROVED, EXACT> fixed-step marchers through a mesh-bounded medium
-//                                  (IntegratorHomogeneousRayMarcherNEE.cpp:10-118,
-//                                   IntegratorHomogeneousRayMarcherImproved.cpp:11-149)
+//   vr_march_kernel<KIND, EXACT>   walks through mesh-bounded media: the two homogeneous fixed-step marchers
+//                                  (IntegratorHomogeneousRayMarcherNEE.cpp:10-118, ...Improved.cpp:11-149), the
+//                                  Perlin-noise marcher (IntegratorHeterogeneousPerlinNoise.cpp:12-168) and the
+//                                  analytic densitySampling (IntegratorDensitySampling.cpp:7-78)
 //   vr_gridmarch_kernel<EMISSION, EXACT> fixed-step marchers through the grid
 //                                  (IntegratorNanoVDBSimple.cpp:10-95, IntegratorNanoVDBEmission.cpp:10-110)
 //   vr_resolve_kernel              per-pixel ordered sum over samples (BaseIntegrator.cpp:71,92,108)
 //
 // Work decomposition: one path sample (one castRay call) per lane.  Sample (s, r, x) owns slot
-// ((s * nrows + r) * width + x) of the per-sample buffer [s][r][x][rgb]; the tracking kernel hands
-// them out sub-sample by sub-sample from the middle rows outwards (see its refill), the marchers in slot order.  Path lengths differ by orders of
-// magnitude (a background pixel ends at the bbox clip, a core pixel takes 10^4 steps), so the
-// tracking kernel is persistent: a lane whose path has ended takes the next item from a global
-// counter (one wave-aggregated atomic per refill) instead of idling until the wave's longest
-// path ends.  Every sample owns one slot of the staging buffer and vr_resolve_kernel sums the
+// ((s * nrows + r) * width + x) of the per-sample buffer [s][r][x][rgb]; vr_resolve_kernel sums the
 // slots of a pixel in sample order, so the image does not depend on which lane ran which path.
+// Path lengths differ by orders of magnitude (a background pixel ends at the bbox clip, a core pixel
+// takes 10^4 steps), so the tracking kernel is persistent: a lane whose path has ended takes the next
+// item of its wave's chunk (one atomic on the global counter per chunk of 128 items) instead of idling
+// until the wave's longest path ends; items go out sub-sample by sub-sample, rows from the middle of
+// the frame outwards (see the refill).  The marchers take their items in slot order.
 #pragma once
 #include "vr_device.h"
 
@@ -115,8 +117,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 // ratio / delta tracking
 // =============================================================================================
 // Lane states.  The kernel alternates between a STEP LOOP, in which every walking lane runs the
-// same code (one iteration of the reference's while loop per trip, camera walk and shadow walk
-// alike), and an EVENT PHASE, in which lanes that left the loop are served together: scatter
+// same code (up to two iterations of the reference's while loop per trip, camera walk and shadow
+// walk alike), and an EVENT PHASE, in which lanes that left the loop are served together: scatter
 // events start their shadow walk, finished shadow walks add the light and pick the new direction,
 // finished paths store their sample and take the next work item.  A lane that meets an event waits
 // (a few iterations) for the phase instead of dragging the whole wave through the long, rare code.
