@@ -29,7 +29,7 @@ enum {
      * oracle/vr_oracle.c in VRO_MATH_SHARED + VRO_RNG_PHILOX mode.  The parity mode. */
     VR_MODE_EXACT = 0,
     /* Same algorithm and random streams, hardware transcendentals (v_log_f32, v_exp_f32,
-     * v_sin_f32, v_cos_f32) and empty-space stepping batched per zero-majorant cell: differs
+     * v_sin_f32, v_cos_f32) and empty-space stepping batched over cubes of empty voxels: differs
      * from EXACT only by rounding.  The production mode. */
     VR_MODE_FAST = 1,
     /* EXACT arithmetic with FAST's batched empty-space stepping: must also be bit-identical to
@@ -52,7 +52,7 @@ const char* vr_backend_last_error(const vr_backend* b);
 
 /* densityGrid / temperatureGrid + densityExtrema + gridBoundingBox (Types.h:141-145;
  * SceneLoader.cpp:207-230).  The voxels are re-laid out in HBM as 8x8x8 bricks and a
- * per-brick majorant grid is built.  temperature may be NULL. */
+ * skip grid (every empty voxel's distance to the nearest non-empty one) is built.  temperature may be NULL. */
 int vr_backend_set_density(vr_backend* b, const vr_grid_desc* density, const vr_grid_desc* temperature);
 
 /* Fills the density grid on the device with the synthetic cloud of BASELINE configs 2-4:

@@ -1,6 +1,6 @@
 // vr_backend.hip — C-ABI implementation (include/vr_backend.h) over the HIP kernels.
 //
-// Host side of the drop-in boundary: copies the scene into HBM (bricked density + majorant grid,
+// Host side of the drop-in boundary: copies the scene into HBM (bricked density + skip grid,
 // threaded BVH), restates the per-frame camera constants of BaseIntegrator::renderPartial, and
 // launches the integrator kernels in sample passes that fit the staging buffer.  Nothing here
 // touches oracle/ — if the GPU or the HIP runtime is missing every entry point fails with
