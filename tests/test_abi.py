@@ -75,3 +75,17 @@ def test_rgb_to_u8_matches_oracle_savefile_conversion(oracle):
     oracle.vro_to_rgb8(ol.fptr(img), 5, 7, want.ctypes.data_as(C.POINTER(C.c_uint8)))
     assert np.array_equal(got, want)
     assert got[0, 0].tolist() == [0, 255, 254]   # truncation, not rounding (BaseIntegrator.cpp:21-23)
+
+
+def test_host_cpp_mirror_compiles():
+    """volume_renderer_amd/host: the C++ mirror of IntegratorFactory / BaseIntegrator over the C-ABI and its
+    example are valid C++17 against include/vr_backend.h (syntax and types only: no GPU, no link)."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        import pytest
+        pytest.skip("g++ not available")
+    src = os.path.join(ROOT, "volume_renderer_amd", "host", "example_render.cpp")
+    r = subprocess.run([gxx, "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
