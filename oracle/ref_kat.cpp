@@ -21,6 +21,7 @@
 #include "MultithreadingHelper.h"
 #include "nanovdb/util/GridBuilder.h"
 #include "tinyobjloader/tiny_obj_loader.h"   // declarations; the implementation TU is compiled in place (Makefile)
+#include "pugixml-1.9/src/pugixml.hpp"       // the reference's XML library; pugixml.cpp is compiled in place too
 
 #include <cstring>
 
@@ -219,6 +220,47 @@ int refk_bridge_obj(const char* obj_path, const char* base_dir, unsigned* counts
     if (dissolve) memcpy(dissolve, soup.shape_dissolve.data(), soup.shape_dissolve.size() * sizeof(float));
     if (diffuse) memcpy(diffuse, soup.shape_diffuse.data(), soup.shape_diffuse.size() * sizeof(float));
     return 0;
+}
+
+/* ---- pugixml conversions as Utils/XMLManager.cpp:16-107 uses them: root = doc.child("options"), then
+ *      root.child(child).text() or .attribute(attr), converted with as_float/as_int/as_uint/as_bool(default).
+ *      kind: 0 float, 1 int, 2 uint, 3 bool.  *present = 0 when the document does not parse. ---- */
+double refk_xml_number(const char* xml, const char* child, const char* attr, int kind, double def, int* present)
+{
+    pugi::xml_document doc;
+    *present = doc.load_string(xml) ? 1 : 0;
+    pugi::xml_node n = doc.child("options").child(child);
+    if (attr) {
+        pugi::xml_attribute a = n.attribute(attr);
+        switch (kind) {
+        case 0: { float f = a.as_float((float)def); return f; }
+        case 1: return a.as_int((int)def);
+        case 2: return a.as_uint((unsigned)def);
+        default: return a.as_bool(def != 0) ? 1 : 0;
+        }
+    }
+    pugi::xml_text t = n.text();
+    switch (kind) {
+    case 0: { float f = t.as_float((float)def); return f; }
+    case 1: return t.as_int((int)def);
+    case 2: return t.as_uint((unsigned)def);
+    default: return t.as_bool(def != 0) ? 1 : 0;
+    }
+}
+/* as_string of the same node/attribute; index selects the index-th <model> under <models> when child == "model" */
+int refk_xml_string(const char* xml, const char* child, const char* attr, int index, char* out, int cap)
+{
+    pugi::xml_document doc;
+    if (!doc.load_string(xml)) return -1;
+    pugi::xml_node root = doc.child("options"), n;
+    if (strcmp(child, "model") == 0) {
+        int i = 0;
+        for (auto m : root.child("models").children("model")) { if (i++ == index) n = m; }
+        if (!n && index >= 0) return -2;
+    } else n = root.child(child);
+    const char* s = attr ? n.attribute(attr).as_string() : n.text().as_string();
+    snprintf(out, (size_t)cap, "%s", s);
+    return (int)strlen(s);
 }
 
 } // extern "C"
