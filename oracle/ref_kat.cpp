@@ -20,6 +20,8 @@
 #include "PerlinNoiseSampler.h"
 #include "MultithreadingHelper.h"
 #include "nanovdb/util/GridBuilder.h"
+#include "nanovdb/util/IO.h"
+#include <fstream>
 #include "tinyobjloader/tiny_obj_loader.h"   // declarations; the implementation TU is compiled in place (Makefile)
 #include "pugixml-1.9/src/pugixml.hpp"       // the reference's XML library; pugixml.cpp is compiled in place too
 
@@ -101,8 +103,16 @@ int refk_chunks(uint32_t chunkSize, uint32_t chunkCount, uint32_t* out_offsets, 
 }
 
 /* ---- NanoVDB: build a FloatGrid from a dense box, the way SceneLoader.cpp:207-230 reads one ---- */
+void* refk_grid_create_named(const float* dense, const int* bmin, const int* bmax, double voxel_size,
+                             const double* origin, float background, const char* name);
 void* refk_grid_create(const float* dense, const int* bmin, const int* bmax, double voxel_size,
                        const double* origin, float background)
+{
+    return refk_grid_create_named(dense, bmin, bmax, voxel_size, origin, background, "density");
+}
+/* the same with a grid name ("density" / "temperature": the names SceneLoader.cpp:208-209 asks readGrid for) */
+void* refk_grid_create_named(const float* dense, const int* bmin, const int* bmax, double voxel_size,
+                             const double* origin, float background, const char* name)
 {
     auto* g = new RefGrid;
     const int ny = bmax[1] - bmin[1] + 1, nz = bmax[2] - bmin[2] + 1;
@@ -116,7 +126,7 @@ void* refk_grid_create(const float* dense, const int* bmin, const int* bmax, dou
                 const float v = dense[((size_t)(i - bmin[0]) * ny + (j - bmin[1])) * nz + (k - bmin[2])];
                 if (v != background) acc.setValue(nanovdb::Coord(i, j, k), v);
             }
-    g->handle = builder.getHandle<>(voxel_size, nanovdb::Vec3d(origin[0], origin[1], origin[2]), "density");
+    g->handle = builder.getHandle<>(voxel_size, nanovdb::Vec3d(origin[0], origin[1], origin[2]), name);
     g->grid = g->handle.grid<float>();
     g->bbox = g->grid->tree().bbox();                          // SceneLoader.cpp:227-229
     g->extrema = nanovdb::getExtrema(*g->grid, g->grid->indexBBox()); // SceneLoader.cpp:219
@@ -185,6 +195,17 @@ void refk_ray_at(const float* eye, const float* dir, float t, float* out)
     out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
 }
 void refk_grid_destroy(void* h) { delete static_cast<RefGrid*>(h); }
+/* nanovdb::io::writeGrid of one or two grids into one .nvdb (uncompressed), the file format SceneLoader.cpp:208 reads */
+int refk_grid_write(const char* path, void* h0, void* h1)
+{
+    try {
+        std::ofstream os(path, std::ios::out | std::ios::binary | std::ios::trunc);
+        if (!os.is_open()) return 1;
+        nanovdb::io::writeGrid(os, static_cast<RefGrid*>(h0)->handle);
+        if (h1) nanovdb::io::writeGrid(os, static_cast<RefGrid*>(h1)->handle);
+        return os.good() ? 0 : 1;
+    } catch (const std::exception&) { return 2; }
+}
 
 /* ---- our reference-side bridge (volume_renderer_amd/host/NanoVdbBridge.hpp) on the reference's types ---- */
 /* describeGrid on the grid above; voxels may be NULL to query the size first */
