@@ -189,18 +189,19 @@ void vro_minstd_canonical_double(uint32_t* state, double* out)
     *out = ret;
 }
 
-/* Philox stream layout (the GPU path's; no reference counterpart):
- *   counter = (pixel, sample, tag, index)   key = 64-bit seed
- *   pixel = (row << 16) | column (absolute), tag = scatter count so far, | 0x80000000 inside the
- *   shadow walk of that scatter event.  Iteration `step` of a walk (every trip through the
- *   reference's while loop counts, empty-space steps included) draws from block index = step / 2:
- *   words (0,1) when step is even, (2,3) when it is odd; first word = free path, second =
- *   collision type (camera walk) or roulette (shadow walk); both use the upper 24 bits.  The
- *   camera walk's Russian roulette at the loop top draws 16 bits from the low bytes of the same
- *   two words.  Side stream: tag | 0x40000000, index 0: words (0,1) = the direction sample of
- *   that scatter event.
- *   A step's draws therefore do not depend on how many draws earlier steps made, which lets the
- *   GPU take runs of empty-space steps at once and walk two iterations on one block.
+/* Random-number layout (the GPU path's; no reference counterpart):
+ *   Philox4x32-10, counter = (pixel, sample, tag, index), key = 64-bit seed;
+ *   pixel = (row << 16) | column (absolute).
+ *   Trackers: one STREAM per walk: tag = scatter count so far for a camera walk, | 0x80000000 for the
+ *   shadow walk of that scatter event.  The Philox block (pixel, sample, tag, 0) is the state of a
+ *   xoshiro128++ generator (Blackman & Vigna 2018, public domain) from which the walk draws in order.
+ *   An iteration that needs random numbers takes TWO words at its first draw: first = free path,
+ *   second = collision type (camera walk) or roulette (shadow walk), both through their upper 24
+ *   bits; the camera walk's Russian roulette at the loop top takes 16 bits from the low bytes of the
+ *   same two words.  Iterations in empty space (sigma <= 0, no roulette) draw nothing, which lets the
+ *   GPU take runs of them at once.  The stream of bounce b+1 starts with the two words of the
+ *   direction sample that ends bounce b.
+ *   Marchers: block (pixel, sample, 0, n) per march step n: word 0 = jitter, word 1 = roulette.
  * In VRO_RNG_REFERENCE mode every draw is the next RandomGenerator::getFloat of the chunk's
  * mt19937, in the reference's call order. */
 typedef struct vro_rng {
@@ -209,7 +210,10 @@ typedef struct vro_rng {
     uint32_t pixel, sample, tag, step, cur;
     uint32_t blk[4], blk_tag, blk_index;
     int      blk_valid;
-    uint32_t saved_tag, saved_step;
+    uint32_t s[4];        /* xoshiro128++ state of the current walk */
+    uint32_t pair[2];     /* the current iteration's two words */
+    int      pair_valid;
+    uint32_t saved_tag, saved_step, saved_s[4];
     uint32_t* mt;         /* 625 words, owned by the row chunk */
     uint32_t* jitter;     /* minstd state, shared (the reference's function-static engine) */
 } vro_rng;
@@ -226,6 +230,37 @@ static const uint32_t* rng_block(vro_rng* g, uint32_t tag, uint32_t index)
     }
     return g->blk;
 }
+/* xoshiro128++ 1.0 as published: result = rotl(s0 + s3, 7) + s0, then the xorshift/rotate state update */
+uint32_t vro_xoshiro128pp_next(uint32_t s[4])
+{
+    const uint32_t sum = s[0] + s[3];
+    const uint32_t result = ((sum << 7) | (sum >> 25)) + s[0];
+    const uint32_t t = s[1] << 9;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = (s[3] << 11) | (s[3] >> 21);
+    return result;
+}
+/* the stream of walk `tag`: its state is the Philox block (pixel, sample, tag, 0) */
+static void rng_seed_stream(vro_rng* g)
+{
+    uint32_t ctr[4] = { g->pixel, g->sample, g->tag, 0u };
+    vro_philox4x32_10(ctr, g->key, g->s);
+    if ((g->s[0] | g->s[1] | g->s[2] | g->s[3]) == 0u) g->s[0] = 1u;
+    g->pair_valid = 0;
+}
+static const uint32_t* rng_pair(vro_rng* g)
+{
+    if (!g->pair_valid) {
+        g->pair[0] = vro_xoshiro128pp_next(g->s);
+        g->pair[1] = vro_xoshiro128pp_next(g->s);
+        g->pair_valid = 1;
+    }
+    return g->pair;
+}
 static void rng_begin_path(vro_rng* g, uint32_t i, uint32_t j, uint32_t s)
 {
     g->pixel = (j << 16) | i;
@@ -233,32 +268,35 @@ static void rng_begin_path(vro_rng* g, uint32_t i, uint32_t j, uint32_t s)
     g->tag = 0;
     g->step = 0;
     g->blk_valid = 0;
+    rng_seed_stream(g);
 }
 /* top of every loop iteration of a walk */
 static void rng_begin_step(vro_rng* g)
 {
     g->cur = g->step++;
+    g->pair_valid = 0;
 }
 /* getFloat(0, 1) of the roulette at the loop top (REF IntegratorRatioTracking.cpp:60) */
 static float rng_roulette(vro_rng* g)
 {
     if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, 0.0f, 1.0f);
-    const uint32_t* w = rng_block(g, g->tag, g->cur >> 1) + (g->cur & 1u) * 2u;
+    const uint32_t* w = rng_pair(g);
     return (float)(((w[0] & 0xffu) << 8) | (w[1] & 0xffu)) * (1.0f / 65536.0f);
 }
 /* getFloat(0.00001f, 1.0f) of the free-path sample (REF :80, :247) */
 static float rng_free_path(vro_rng* g)
 {
     if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, 0.00001f, 1.0f);
-    return (unit24(rng_block(g, g->tag, g->cur >> 1)[(g->cur & 1u) * 2u]) * (1.0f - 0.00001f)) + 0.00001f;
+    return (unit24(rng_pair(g)[0]) * (1.0f - 0.00001f)) + 0.00001f;
 }
 /* getFloat(0, 1) of the collision type (REF :108) / of the shadow walk's roulette (REF :275) */
 static float rng_event(vro_rng* g)
 {
     if (g->mode == VRO_RNG_REFERENCE) return vro_reference_get_float(g->mt, 0.0f, 1.0f);
-    return (unit24(rng_block(g, g->tag, g->cur >> 1)[(g->cur & 1u) * 2u + 1u]) * (1.0f - 0.0f)) + 0.0f;
+    return (unit24(rng_pair(g)[1]) * (1.0f - 0.0f)) + 0.0f;
 }
-/* the two getFloat(0, 0.9999f) of sampleHenyeyGreenstein (REF Utils/DirectionSampler.cpp:43,58) */
+/* the two getFloat(0, 0.9999f) of sampleHenyeyGreenstein (REF Utils/DirectionSampler.cpp:43,58):
+ * the first two words of the NEXT bounce's stream, which starts here */
 static void rng_direction(vro_rng* g, float* xi1, float* xi2)
 {
     if (g->mode == VRO_RNG_REFERENCE) {
@@ -266,32 +304,28 @@ static void rng_direction(vro_rng* g, float* xi1, float* xi2)
         *xi2 = vro_reference_get_float(g->mt, 0.0f, 0.9999f);
         return;
     }
-    uint32_t ctr[4] = { g->pixel, g->sample, g->tag | 0x40000000u, 0u }, w[4];
-    vro_philox4x32_10(ctr, g->key, w);
-    *xi1 = (unit24(w[0]) * (0.9999f - 0.0f)) + 0.0f;
-    *xi2 = (unit24(w[1]) * (0.9999f - 0.0f)) + 0.0f;
-}
-/* a new stream per scatter event ("bounce") */
-static void rng_next_bounce(vro_rng* g)
-{
     g->tag += 1;
     g->step = 0;
-    g->blk_valid = 0;
+    rng_seed_stream(g);
+    *xi1 = (unit24(vro_xoshiro128pp_next(g->s)) * (0.9999f - 0.0f)) + 0.0f;
+    *xi2 = (unit24(vro_xoshiro128pp_next(g->s)) * (0.9999f - 0.0f)) + 0.0f;
 }
 /* the shadow walk of bounce b draws from stream (b | 0x80000000) */
 static void rng_push_shadow(vro_rng* g)
 {
     g->saved_tag = g->tag;
     g->saved_step = g->step;
+    memcpy(g->saved_s, g->s, sizeof g->s);
     g->tag |= 0x80000000u;
     g->step = 0;
-    g->blk_valid = 0;
+    rng_seed_stream(g);
 }
 static void rng_pop_shadow(vro_rng* g)
 {
     g->tag = g->saved_tag;
     g->step = g->saved_step;
-    g->blk_valid = 0;
+    memcpy(g->s, g->saved_s, sizeof g->s);
+    g->pair_valid = 0;
 }
 /* Improved marcher, march step n: word 0 = jitter (own engine in the reference), word 1 = roulette */
 static double rng_march_jitter(vro_rng* g, uint32_t n)
@@ -874,7 +908,6 @@ static v3 cast_ray_delta(path_ctx* d)
             }
             d->rayDirection = scattered;                                    /* :146 */
             iRay = ray_make(iRayOrigin, scattered, 1e-5f, FLT_MAX);         /* :147 */
-            rng_next_bounce(d->rng);
             if (!ray_clip(&iRay, grid)) { terminated = 1; break; }          /* :150-155 */
             tFar = iRay.t0;                                                 /* :157 */
         }
@@ -1034,8 +1067,7 @@ static v3 cast_ray_ratio(path_ctx* d)
                 }
                 d->rayDirection = scattered;                                /* :178 */
                 iRay = ray_make(iRayOrigin, scattered, 1e-5f, FLT_MAX);     /* :179 */
-                rng_next_bounce(d->rng);
-                if (!ray_clip(&iRay, grid)) { terminated = 1; break; }      /* :182-187 */
+                    if (!ray_clip(&iRay, grid)) { terminated = 1; break; }      /* :182-187 */
                 tFar = iRay.t0;                                             /* :189 */
             }
         }

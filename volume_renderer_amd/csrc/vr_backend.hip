@@ -489,6 +489,7 @@ int validate(vr_backend* b, const vr_options_pod* o, int integrator)
     if (!o) return fail(b, VR_ERR_INVALID_ARG, "options == NULL");
     if (integrator < 0 || integrator >= VR_INTEGRATOR_COUNT) return fail(b, VR_ERR_INVALID_ARG, "unknown integrator id %d", integrator);
     if (o->width == 0 || o->height == 0 || o->rayPerPixelCount == 0) return fail(b, VR_ERR_INVALID_ARG, "width, height and rayPerPixelCount must be > 0");
+    if (o->rayPerPixelCount > (1u << 20)) return fail(b, VR_ERR_INVALID_ARG, "rayPerPixelCount above 2^20 (the sample index has 20 bits in the kernels' stream id)");
     if (o->width + o->widthStartOffset > 65536u || o->height + o->heightStartOffset > 65536u)
         return fail(b, VR_ERR_INVALID_ARG, "image coordinates must stay below 65536 (Philox pixel key)");
     if (o->maxDepth > 255) return fail(b, VR_ERR_INVALID_ARG, "maxDepth is a uint8_t in the reference (Types.h:101)");

@@ -62,21 +62,36 @@ struct Math<false> {
     static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 };
 
-// ---- Philox4x32-10 (Salmon et al. 2011) ------------------------------------------------------
+// ---- random numbers: Philox4x32-10 keys the streams, xoshiro128++ runs them --------------------
 // Replaces RandomGenerator (Utils/RandomGenerator.cpp:4-14): only the ranges of its draws are
-// contract.  Stream layout (mirrored by the oracle's vro_rng):
-//   counter = (pixel, sample, tag, index), key = 64-bit seed
-//   pixel = (row << 16) | column in absolute image coordinates, so a pixel's stream does not depend
-//   on crop, row partition or GPU count; tag = scatter count so far, | 0x80000000 inside the shadow
-//   walk of that scatter event.  Iteration `step` of a walk (counted as the reference iterates,
-//   empty-space steps included) draws from block index = step / 2: words (0,1) when step is even,
-//   (2,3) when it is odd; first word = free path, second = collision type (camera walk) or
-//   roulette (shadow walk); both use the upper 24 bits.  The camera walk's roulette at the loop
-//   top (rare) draws 16 bits from the low bytes of the same two words.  Side stream:
-//   tag | 0x40000000, index 0: words (0,1) = the direction sample of that scatter event.
-// A step's draws do not depend on how many draws earlier steps made, so runs of empty-space steps
-// can be taken at once; the tracking kernel generates one block per trip and walks up to two
-// iterations on it.
+// contract.  Layout (mirrored by the oracle's vro_rng):
+//   Philox4x32-10 (Salmon et al. 2011), counter = (pixel, sample, tag, index), key = 64-bit seed;
+//   pixel = (row << 16) | column in absolute image coordinates, so a pixel's streams do not depend
+//   on crop, row partition or GPU count.
+//   Trackers: one STREAM per walk — tag = scatter count so far ("bounce") for a camera walk,
+//   | 0x80000000 for the shadow walk of that scatter event.  The Philox block (pixel, sample, tag, 0)
+//   is the 128-bit state of a xoshiro128++ generator (Blackman & Vigna 2018); the walk draws from it
+//   in order.  An iteration that needs random numbers (sigma > 0, or the camera walk's roulette) takes
+//   TWO words: first = free path, second = collision type (camera walk) or roulette (shadow walk), both
+//   through their upper 24 bits; the camera walk's roulette at the loop top uses 16 bits from the low
+//   bytes of the same two words.  Empty-space iterations draw nothing, so runs of them can be taken at
+//   once.  The stream of bounce b+1 starts with the two words of the direction sample that ends bounce b.
+//   Marchers: block (pixel, sample, 0, n) per march step n: word 0 jitter, word 1 roulette.
+// Ten Philox rounds per two iterations were half of the step loop's instructions; a xoshiro word is
+// nine full-rate instructions.
+__device__ __forceinline__ uint32_t xoshiro128pp_next(uint32_t& s0, uint32_t& s1, uint32_t& s2, uint32_t& s3)
+{
+    const uint32_t sum = s0 + s3;
+    const uint32_t result = __builtin_amdgcn_alignbit(sum, sum, 32 - 7) + s0;      // rotl(s0 + s3, 7) + s0
+    const uint32_t t = s1 << 9;
+    const uint32_t x3 = s3 ^ s1;                                                   // s3 ^= s1
+    const uint32_t n1 = __builtin_amdgcn_bitop3_b32(s1, s2, s0, 0x96);             // s2 ^= s0; s1 ^= s2
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32(s2, s0, t, 0x96);              // s2 ^= s0; ...; s2 ^= t
+    s0 ^= x3;                                                                      // s0 ^= s3
+    s1 = n1; s2 = n2;
+    s3 = __builtin_amdgcn_alignbit(x3, x3, 32 - 11);                               // s3 = rotl(s3, 11)
+    return result;
+}
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
 {

@@ -175,15 +175,24 @@ vr_track_kernel(const TrackParams p)
     // and, per axis, (dir > 0 ? 1 - slack : slack) - eye, so that the ray leaves the shrunk voxel
     // whose corner is f at t = (f + span_off) * inv
     f3       inv = mk3(0, 0, 1), span_off = mk3(0, 0, 0);
-    float    t = 0, t1 = 0, t0 = 0;     // tFar, iRay.t1(), iRay.t0()
+    float    t = 0, t1 = 0;             // tFar, iRay.t1()
+    // iRay.t0() of the camera ray, read when its shadow walk starts — and from there until that walk's
+    // light is added, the shadow walk's transmission: the two are never alive together, but only the
+    // author can know that of lanes in different phases
+    float    t0 = 0;
+    float&   Tsh = t0;
     f3       wdir = mk3(0, 0, 1);       // data->rayDirection
     f3       radiance = mk3(0, 0, 0);   // data->radiance / result
-    float    T = 1.0f, Tsh = 1.0f;      // data->transmission, shadow-walk transmission
+    float    T = 1.0f;                  // data->transmission
     float    pdf = 1.0f;                // data->rayPDF (only read with useImportanceSampling)
     int      depth_remaining = 0;
     f3       scatter_p = mk3(0, 0, 0);  // iRay(tFar) of the pending scatter event
     float    scatter_len = 0;           // its pathLength (ST_ABSORBED: mu_a of the absorbing step)
-    uint32_t rng_pixel = 0, rng_sample = 0, rng_tag = 0, rng_step = 0;   // Philox counter (vr_device.h)
+    // names the walk's stream (vr_device.h): pixel, and in one word sample (bits 0-19), bounce (20-27)
+    // and the shadow-walk flag (bit 31)
+    uint32_t rng_pixel = 0, rng_ts = 0;
+    uint32_t rng_step = 0;                                 // iterations of the walk so far
+    uint32_t xs0 = 1, xs1 = 0, xs2 = 0, xs3 = 0;           // the stream's xoshiro128++ state
     // density at iRay(tFar), fetched at the END of the previous trip so that its latency hides
     // behind the loop overhead and the next trip's Philox block
     float    cur_val = 0.0f;
@@ -225,6 +234,11 @@ vr_track_kernel(const TrackParams p)
         const float cx = floorf(q.x) + copysignf(radius, dir.x), cy = floorf(q.y) + copysignf(radius, dir.y),
                     cz = floorf(q.z) + copysignf(radius, dir.z);
         return fminf(fminf((cx + span_off.x) * inv.x, (cy + span_off.y) * inv.y), (cz + span_off.z) * inv.z);
+    };
+    // a walk's stream: the Philox block of (pixel, sample, tag) is the generator's state
+    auto seed_stream = [&]() {
+        philox4x32_10(rng_pixel, rng_ts & 0xfffffu, ((rng_ts >> 20) & 0xffu) | (rng_ts & 0x80000000u), 0u, k0, k1, xs0, xs1, xs2, xs3);
+        if ((xs0 | xs1 | xs2 | xs3) == 0u) xs0 = 1u;   // the one state xoshiro cannot leave
     };
     auto set_ray = [&](f3 e, f3 d, float a, float b) {
         eye = e; dir = d; t = a; t1 = b;
@@ -270,12 +284,13 @@ vr_track_kernel(const TrackParams p)
                 n_shadow++;
                 const f3 so = ray_at(eye, dir, t0);                               // :226 (segment START)
                 n_lookups += rng_step;
-                rng_tag |= 0x80000000u; rng_step = 0;
+                rng_ts |= 0x80000000u; rng_step = 0;
                 float c0 = 1e-5f, c1 = VR_FLT_MAX;
                 if (!ray_clip(so, light, c0, c1, c->bmin, c->bmax1)) {            // :229-232
                     Tsh = 1.0f; st = ST_SHADOW_DONE;
                 } else {
                     shadow = true; Tsh = 1.0f; st = ST_WALK;
+                    seed_stream();
                     set_ray(so, light, c0, c1);
                 }
             }
@@ -285,7 +300,7 @@ vr_track_kernel(const TrackParams p)
             if (st == ST_SHADOW_DONE) {
                 const TrackCold* c = opaque(p.cold);
                 if (INTEG == INTEG_RATIO) {
-                    rng_tag &= 0x7fffffffu;   // back on the camera stream
+                    rng_ts &= 0x7fffffffu;    // back on the camera walk
                     const f3 light = mk3(c->light[0], c->light[1], c->light[2]);
                     const float cos_theta = dot3(wdir, light);                            // :144
                     const float hg = hg_phase(c->g, cos_theta);                           // :145
@@ -294,8 +309,11 @@ vr_track_kernel(const TrackParams p)
                     nee = scale3(nee, hg);
                     radiance = add3(radiance, nee);
                 }
-                uint32_t h0, h1, h2, h3;
-                philox4x32_10(rng_pixel, rng_sample, rng_tag | 0x40000000u, 0u, k0, k1, h0, h1, h2, h3);
+                // the next bounce's stream starts with the direction sample
+                n_lookups += rng_step;
+                rng_ts += 1u << 20; rng_step = 0;
+                seed_stream();
+                const uint32_t h0 = xoshiro128pp_next(xs0, xs1, xs2, xs3), h1 = xoshiro128pp_next(xs0, xs1, xs2, xs3);
                 const float xi1 = in_range(h0, 0.0f, 0.9999f);
                 const float xi2 = in_range(h1, 0.0f, 0.9999f);
                 const f3 scattered = hg_sample<EXACT>(c->g, wdir, xi1, xi2);              // :156-159
@@ -314,8 +332,6 @@ vr_track_kernel(const TrackParams p)
                     pdf *= hg_phase(c->g, cos_pdf);
                 }
                 wdir = scattered;                                                         // :178
-                n_lookups += rng_step;
-                rng_tag += 1; rng_step = 0;
                 shadow = false;
                 float c0 = 1e-5f, c1 = VR_FLT_MAX;
                 if (!ray_clip(scatter_p, scattered, c0, c1, c->bmin, c->bmax1)) {         // :182-187 "scattering failed"
@@ -404,7 +420,8 @@ vr_track_kernel(const TrackParams p)
                         radiance = mk3(0, 0, 0);
                         T = 1.0f;
                         depth_remaining = (int)c->max_depth;
-                        rng_pixel = (cj << 16) | ci; rng_sample = s; rng_tag = 0; rng_step = 0;
+                        rng_pixel = (cj << 16) | ci; rng_ts = s; rng_step = 0;
+                        seed_stream();
                         pdf = 1.0f;                                                       // :14
                         set_ray(ieye, ndir, c0, c1);
                     }
@@ -414,41 +431,37 @@ vr_track_kernel(const TrackParams p)
         if (!__any(st == ST_WALK)) break;   // every lane exhausted (events were all served above)
 
         // =========================== step loop ===========================
-        // One trip = one Philox block = up to TWO iterations of the reference's while loop: iteration
-        // `step` of a walk draws words (0,1) of block step/2 when step is even, words (2,3) when it
-        // is odd.  A lane that enters a trip on an even step can take both halves, one on an odd
-        // step only the first.  Few lanes are in empty space at any time but nearly every wave
-        // has one, so the empty-space code runs once per trip, after the two halves: a lane that
-        // finds sigma <= 0 sits out the rest of the trip and takes its run there.
+        // One trip = up to TWO iterations of the reference's while loop.  Few lanes are in empty space at
+        // any time but nearly every wave has one, so the empty-space code runs once per trip, after
+        // the two halves: a lane that finds sigma <= 0 sits out the rest of the trip and takes its
+        // run there.
         if (st == ST_WALK && rng_step > p.work.step_limit) { n_limit++; st = ST_FINISHED; }   // safety cap, once per round
 #pragma unroll 1
         for (int it = 0; it < p.round_max; ++it) {
-            uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-            const uint32_t block = rng_step >> 1;
-            if (st == ST_WALK) philox4x32_10(rng_pixel, rng_sample, rng_tag, block, k0, k1, w0, w1, w2, w3);
             bool empty = false;     // this lane's current iteration is an empty-space step, still to be taken
             bool parked = false;    // this lane has left its voxel and waits for the lookup at the end of the trip
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                if (st != ST_WALK || empty || parked || (half && (rng_step >> 1) != block)) continue;
-                // (the second half only ever sees odd steps)
-                const bool     odd = half || (rng_step & 1u);
-                const uint32_t w_path = odd ? w2 : w0, w_event = odd ? w3 : w1;
+                if (st != ST_WALK || empty || parked) continue;
                 const bool in_shadow = (INTEG == INTEG_RATIO) && shadow;
 
                 // sigma = multiplier * acc.getValue(Coord::Floor(iRay(tFar)))                :71 / :238
                 const float mult = in_shadow ? p.shadow_mult : p.light_mult;
                 const float sigma = mult * cur_val;
 
-                if (INTEG == INTEG_RATIO && !in_shadow && T < 0.05f) {
+                const bool roulette = INTEG == INTEG_RATIO && !in_shadow && T < 0.05f;
+                if (!roulette && !(sigma > 0.0f)) { empty = true; continue; }
+                // the iteration's two words
+                const uint32_t w_path = xoshiro128pp_next(xs0, xs1, xs2, xs3), w_event = xoshiro128pp_next(xs0, xs1, xs2, xs3);
+                if (roulette) {
                     // Russian roulette on the camera walk     IntegratorRatioTracking.cpp:57-69
                     // (a path it ends does not count the lookup above, as in the reference)
                     const float q = 0.75f;
                     if (roulette16(w_path, w_event) < q) T = 0.0f;
                     else T /= 1.0f - q;
                     if (T <= 0.0f) { st = ST_FINISHED; continue; }
+                    if (!(sigma > 0.0f)) { empty = true; continue; }
                 }
-                if (!(sigma > 0.0f)) { empty = true; continue; }
 
                 // free path: camera walk over the global majorant, shadow walk over mu_t   :80-82 / :247-249
                 const float tmin = in_shadow ? p.t_min * 5 : p.t_min;                         // :216
