@@ -624,8 +624,6 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             p.sigma_maj = b->max_value * (o->sigma_a + o->sigma_s);          // IntegratorRatioTracking.cpp:42-45
             p.t_min = o->stepSizeMin; p.t_max = o->stepSizeMax; p.step_mult = o->stepSizeMultiplier;
             p.light_mult = o->lightRayDensityMultiplier; p.shadow_mult = o->shadowRayDensityMultiplier;
-            p.round_max = tune_int("VR_TUNE_ROUND_MAX", VR_ROUND_MAX);
-            p.round_events = tune_int("VR_TUNE_ROUND_EVENTS", VR_ROUND_EVENTS);
             // typical free path (index units) well under a voxel: remember each voxel's t-interval
             bool span = false;
             {
@@ -633,8 +631,13 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 const float typical = std::min(std::max(o->stepSizeMin, mean_free), o->stepSizeMax);
                 span = typical < 0.25f && span_ok;
             }
-            void (*kern)(const TrackParams);
             const bool ratio = integrator == VR_INTEGRATOR_RATIO_TRACKING;
+            // a round of the step loop ends after round_max trips or when round_events lanes wait for the
+            // event phase (measured per regime: sub-voxel steps have long trips and rare events, voxel-sized
+            // steps one iteration per trip and an event every few iterations)
+            p.round_max = tune_int("VR_TUNE_ROUND_MAX", span ? VR_ROUND_MAX : 2 * VR_ROUND_MAX);
+            p.round_events = tune_int("VR_TUNE_ROUND_EVENTS", span ? (ratio ? 16 : VR_ROUND_EVENTS) : 2 * VR_ROUND_EVENTS);
+            void (*kern)(const TrackParams);
             // empty-space runs read the skip grid, whose empty voxels only keep the sign of sigma for
             // multipliers >= 0 (the shadow multiplier is only read by the ratio tracker)
             const bool skip_ok = span_ok && o->lightRayDensityMultiplier >= 0.0f && (!ratio || o->shadowRayDensityMultiplier >= 0.0f);

@@ -129,6 +129,18 @@ enum {
 };
 #define VR_ROUND_MAX 48      // step-loop trips before the event phase runs regardless
 #define VR_ROUND_EVENTS 12   // ... or as soon as this many lanes wait for it
+// Iterations of the reference's loop per trip.  A trip ends with ONE empty-space service and ONE voxel
+// lookup for the whole wave, so more iterations per trip amortise those — as long as lanes rarely leave
+// their voxel (SPAN: sub-voxel steps), because a lane that does sits out the rest of the trip.
+#ifndef VR_TRIP_ITERS_SPAN_RATIO
+#define VR_TRIP_ITERS_SPAN_RATIO 3
+#endif
+#ifndef VR_TRIP_ITERS_SPAN_DELTA
+#define VR_TRIP_ITERS_SPAN_DELTA 6
+#endif
+#ifndef VR_TRIP_ITERS_PLAIN
+#define VR_TRIP_ITERS_PLAIN 1
+#endif
 
 // hide a pointer's provenance: loads through it stay ordinary vector loads inside the phase
 template <typename T>
@@ -157,6 +169,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VR_TRA
 vr_track_kernel(const TrackParams p)
 {
     typedef Math<EXACT> M;
+    constexpr int  VR_TRIP_ITERS = SPAN ? (INTEG == INTEG_RATIO ? VR_TRIP_ITERS_SPAN_RATIO : VR_TRIP_ITERS_SPAN_DELTA) : VR_TRIP_ITERS_PLAIN;
     const int      lane = threadIdx.x & 63;
     const uint32_t k0 = p.work.key0, k1 = p.work.key1;
     // FAST arithmetic: constants of the step loop folded once (wave-uniform)
@@ -175,15 +188,12 @@ vr_track_kernel(const TrackParams p)
     // and, per axis, (dir > 0 ? 1 - slack : slack) - eye, so that the ray leaves the shrunk voxel
     // whose corner is f at t = (f + span_off) * inv
     f3       inv = mk3(0, 0, 1), span_off = mk3(0, 0, 0);
-    float    t = 0, t1 = 0;             // tFar, iRay.t1()
-    // iRay.t0() of the camera ray, read when its shadow walk starts — and from there until that walk's
-    // light is added, the shadow walk's transmission: the two are never alive together, but only the
-    // author can know that of lanes in different phases
-    float    t0 = 0;
-    float&   Tsh = t0;
+    float    t = 0, t1 = 0, t0 = 0;     // tFar, iRay.t1(), iRay.t0()
     f3       wdir = mk3(0, 0, 1);       // data->rayDirection
     f3       radiance = mk3(0, 0, 0);   // data->radiance / result
-    float    T = 1.0f;                  // data->transmission
+    // data->transmission, shadow-walk transmission.  (Tsh and t0 are never alive together, but sharing one
+    // register between them measured 2 % slower: the allocator's choices elsewhere changed.)
+    float    T = 1.0f, Tsh = 1.0f;
     float    pdf = 1.0f;                // data->rayPDF (only read with useImportanceSampling)
     int      depth_remaining = 0;
     f3       scatter_p = mk3(0, 0, 0);  // iRay(tFar) of the pending scatter event
@@ -441,7 +451,7 @@ vr_track_kernel(const TrackParams p)
             bool empty = false;     // this lane's current iteration is an empty-space step, still to be taken
             bool parked = false;    // this lane has left its voxel and waits for the lookup at the end of the trip
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < VR_TRIP_ITERS; ++half) {
                 if (st != ST_WALK || empty || parked) continue;
                 const bool in_shadow = (INTEG == INTEG_RATIO) && shadow;
 
@@ -483,7 +493,7 @@ vr_track_kernel(const TrackParams p)
                 // the second iteration's voxel.  With sub-voxel steps (use_span) few lanes need one,
                 // yet nearly every wave has such a lane: it sits out the second half instead and
                 // is served by the lookup at the end of the trip.
-                if (half == 0 && t <= t1) {
+                if (half + 1 < VR_TRIP_ITERS && t <= t1) {
                     if (SPAN) parked = !(t < t_span);
                     else prefetch();
                 }
