@@ -194,7 +194,8 @@ void vro_minstd_canonical_double(uint32_t* state, double* out)
  *   pixel = (row << 16) | column (absolute).
  *   Trackers: one STREAM per walk: tag = scatter count so far for a camera walk, | 0x80000000 for the
  *   shadow walk of that scatter event.  The Philox block (pixel, sample, tag, 0) is the state of a
- *   xoshiro128++ generator (Blackman & Vigna 2018, public domain) from which the walk draws in order.
+ *   xoshiro128+ generator (Blackman & Vigna 2018, public domain: their generator for floats taken from
+ *   the upper bits) from which the walk draws in order.
  *   An iteration that needs random numbers takes TWO words at its first draw: first = free path,
  *   second = collision type (camera walk) or roulette (shadow walk), both through their upper 24
  *   bits; the camera walk's Russian roulette at the loop top takes 16 bits from the low bytes of the
@@ -210,7 +211,7 @@ typedef struct vro_rng {
     uint32_t pixel, sample, tag, step, cur;
     uint32_t blk[4], blk_tag, blk_index;
     int      blk_valid;
-    uint32_t s[4];        /* xoshiro128++ state of the current walk */
+    uint32_t s[4];        /* xoshiro128+ state of the current walk */
     uint32_t pair[2];     /* the current iteration's two words */
     int      pair_valid;
     uint32_t saved_tag, saved_step, saved_s[4];
@@ -230,11 +231,10 @@ static const uint32_t* rng_block(vro_rng* g, uint32_t tag, uint32_t index)
     }
     return g->blk;
 }
-/* xoshiro128++ 1.0 as published: result = rotl(s0 + s3, 7) + s0, then the xorshift/rotate state update */
-uint32_t vro_xoshiro128pp_next(uint32_t s[4])
+/* xoshiro128+ 1.0 as published: result = s0 + s3, then the xorshift/rotate state update */
+uint32_t vro_xoshiro128p_next(uint32_t s[4])
 {
-    const uint32_t sum = s[0] + s[3];
-    const uint32_t result = ((sum << 7) | (sum >> 25)) + s[0];
+    const uint32_t result = s[0] + s[3];
     const uint32_t t = s[1] << 9;
     s[2] ^= s[0];
     s[3] ^= s[1];
@@ -255,8 +255,8 @@ static void rng_seed_stream(vro_rng* g)
 static const uint32_t* rng_pair(vro_rng* g)
 {
     if (!g->pair_valid) {
-        g->pair[0] = vro_xoshiro128pp_next(g->s);
-        g->pair[1] = vro_xoshiro128pp_next(g->s);
+        g->pair[0] = vro_xoshiro128p_next(g->s);
+        g->pair[1] = vro_xoshiro128p_next(g->s);
         g->pair_valid = 1;
     }
     return g->pair;
@@ -307,8 +307,8 @@ static void rng_direction(vro_rng* g, float* xi1, float* xi2)
     g->tag += 1;
     g->step = 0;
     rng_seed_stream(g);
-    *xi1 = (unit24(vro_xoshiro128pp_next(g->s)) * (0.9999f - 0.0f)) + 0.0f;
-    *xi2 = (unit24(vro_xoshiro128pp_next(g->s)) * (0.9999f - 0.0f)) + 0.0f;
+    *xi1 = (unit24(vro_xoshiro128p_next(g->s)) * (0.9999f - 0.0f)) + 0.0f;
+    *xi2 = (unit24(vro_xoshiro128p_next(g->s)) * (0.9999f - 0.0f)) + 0.0f;
 }
 /* the shadow walk of bounce b draws from stream (b | 0x80000000) */
 static void rng_push_shadow(vro_rng* g)

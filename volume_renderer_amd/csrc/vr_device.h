@@ -62,7 +62,7 @@ struct Math<false> {
     static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 };
 
-// ---- random numbers: Philox4x32-10 keys the streams, xoshiro128++ runs them --------------------
+// ---- random numbers: Philox4x32-10 keys the streams, xoshiro128+ runs them --------------------
 // Replaces RandomGenerator (Utils/RandomGenerator.cpp:4-14): only the ranges of its draws are
 // contract.  Layout (mirrored by the oracle's vro_rng):
 //   Philox4x32-10 (Salmon et al. 2011), counter = (pixel, sample, tag, index), key = 64-bit seed;
@@ -70,19 +70,19 @@ struct Math<false> {
 //   on crop, row partition or GPU count.
 //   Trackers: one STREAM per walk — tag = scatter count so far ("bounce") for a camera walk,
 //   | 0x80000000 for the shadow walk of that scatter event.  The Philox block (pixel, sample, tag, 0)
-//   is the 128-bit state of a xoshiro128++ generator (Blackman & Vigna 2018); the walk draws from it
+//   is the 128-bit state of a xoshiro128+ generator (Blackman & Vigna 2018: their generator for
+//   floating-point numbers taken from the upper bits, which is the use here); the walk draws from it
 //   in order.  An iteration that needs random numbers (sigma > 0, or the camera walk's roulette) takes
 //   TWO words: first = free path, second = collision type (camera walk) or roulette (shadow walk), both
 //   through their upper 24 bits; the camera walk's roulette at the loop top uses 16 bits from the low
 //   bytes of the same two words.  Empty-space iterations draw nothing, so runs of them can be taken at
 //   once.  The stream of bounce b+1 starts with the two words of the direction sample that ends bounce b.
 //   Marchers: block (pixel, sample, 0, n) per march step n: word 0 jitter, word 1 roulette.
-// Ten Philox rounds per two iterations were half of the step loop's instructions; a xoshiro word is
-// nine full-rate instructions.
-__device__ __forceinline__ uint32_t xoshiro128pp_next(uint32_t& s0, uint32_t& s1, uint32_t& s2, uint32_t& s3)
+// The step loop is bound by its VALU instruction count (SQ_ACTIVE_INST_VALU = all SIMD cycles): a
+// xoshiro128+ word is seven instructions, and Philox runs once per walk instead of once per two iterations.
+__device__ __forceinline__ uint32_t xoshiro128p_next(uint32_t& s0, uint32_t& s1, uint32_t& s2, uint32_t& s3)
 {
-    const uint32_t sum = s0 + s3;
-    const uint32_t result = __builtin_amdgcn_alignbit(sum, sum, 32 - 7) + s0;      // rotl(s0 + s3, 7) + s0
+    const uint32_t result = s0 + s3;
     const uint32_t t = s1 << 9;
     const uint32_t x3 = s3 ^ s1;                                                   // s3 ^= s1
     const uint32_t n1 = __builtin_amdgcn_bitop3_b32(s1, s2, s0, 0x96);             // s2 ^= s0; s1 ^= s2

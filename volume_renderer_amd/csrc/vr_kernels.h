@@ -202,7 +202,7 @@ vr_track_kernel(const TrackParams p)
     // and the shadow-walk flag (bit 31)
     uint32_t rng_pixel = 0, rng_ts = 0;
     uint32_t rng_step = 0;                                 // iterations of the walk so far
-    uint32_t xs0 = 1, xs1 = 0, xs2 = 0, xs3 = 0;           // the stream's xoshiro128++ state
+    uint32_t xs0 = 1, xs1 = 0, xs2 = 0, xs3 = 0;           // the stream's xoshiro128+ state
     // density at iRay(tFar), fetched at the END of the previous trip so that its latency hides
     // behind the loop overhead and the next trip's Philox block
     float    cur_val = 0.0f;
@@ -323,7 +323,7 @@ vr_track_kernel(const TrackParams p)
                 n_lookups += rng_step;
                 rng_ts += 1u << 20; rng_step = 0;
                 seed_stream();
-                const uint32_t h0 = xoshiro128pp_next(xs0, xs1, xs2, xs3), h1 = xoshiro128pp_next(xs0, xs1, xs2, xs3);
+                const uint32_t h0 = xoshiro128p_next(xs0, xs1, xs2, xs3), h1 = xoshiro128p_next(xs0, xs1, xs2, xs3);
                 const float xi1 = in_range(h0, 0.0f, 0.9999f);
                 const float xi2 = in_range(h1, 0.0f, 0.9999f);
                 const f3 scattered = hg_sample<EXACT>(c->g, wdir, xi1, xi2);              // :156-159
@@ -462,7 +462,7 @@ vr_track_kernel(const TrackParams p)
                 const bool roulette = INTEG == INTEG_RATIO && !in_shadow && T < 0.05f;
                 if (!roulette && !(sigma > 0.0f)) { empty = true; continue; }
                 // the iteration's two words
-                const uint32_t w_path = xoshiro128pp_next(xs0, xs1, xs2, xs3), w_event = xoshiro128pp_next(xs0, xs1, xs2, xs3);
+                const uint32_t w_path = xoshiro128p_next(xs0, xs1, xs2, xs3), w_event = xoshiro128p_next(xs0, xs1, xs2, xs3);
                 if (roulette) {
                     // Russian roulette on the camera walk     IntegratorRatioTracking.cpp:57-69
                     // (a path it ends does not count the lookup above, as in the reference)
