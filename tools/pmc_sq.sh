@@ -12,7 +12,7 @@ for d in ("$O/pmc_a","$O/pmc_b"):
     agg=collections.defaultdict(float)
     for f in glob.glob(d+"/**/*counter_collection.csv",recursive=True):
         for r in csv.DictReader(open(f)):
-            if "vr_track_kernel" in r["Kernel_Name"]:
+            if "${KERNEL:-vr_track_kernel}" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]]+=float(r["Counter_Value"])
     for k,v in sorted(agg.items()): print(k, "%.4g"%v)
 PY

@@ -596,7 +596,12 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 integrator == VR_INTEGRATOR_NANOVDB_SIMPLE
                     ? (exact ? vr_gridmarch_kernel<false, true> : vr_gridmarch_kernel<false, false>)
                     : (exact ? vr_gridmarch_kernel<true, true> : vr_gridmarch_kernel<true, false>);
-            const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(8ull * b->num_cu, (work.nitems + 255ull) / 256));
+            // persistent waves, each drawing 8x8-pixel tiles from the launch's counter
+            int per_cu = 8;
+            rc = launch_cap(b, kern, p, per_cu);
+            if (rc) return rc;
+            const uint64_t ntiles = (uint64_t)((cam.width + 7) / 8) * ((cam.nrows + 7) / 8) * sc;
+            const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_cu * b->num_cu, (ntiles + 3) / 4));
             HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
             HIP_TRY(b, hipGetLastError());
@@ -685,7 +690,12 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 : integrator == VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE
                     ? (exact ? vr_march_kernel<MARCH_PERLIN, true> : vr_march_kernel<MARCH_PERLIN, false>)
                     : (exact ? vr_march_kernel<MARCH_DENSITY, true> : vr_march_kernel<MARCH_DENSITY, false>);
-            const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(8ull * b->num_cu, (work.nitems + 255ull) / 256));
+            // persistent waves, each drawing 8x8-pixel tiles from the launch's counter
+            int per_cu = 8;
+            rc = launch_cap(b, kern, p, per_cu);
+            if (rc) return rc;
+            const uint64_t ntiles = (uint64_t)((cam.width + 7) / 8) * ((cam.nrows + 7) / 8) * sc;
+            const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_cu * b->num_cu, (ntiles + 3) / 4));
             HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
             HIP_TRY(b, hipGetLastError());

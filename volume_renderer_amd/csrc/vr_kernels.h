@@ -921,11 +921,24 @@ __global__ void __launch_bounds__(256) vr_gridmarch_kernel(const GridMarchParams
     const float l_inv_length = 1.0f / l_length;
     const f3    l_dir = mk3(l_inv_length * l_idir.x, l_inv_length * l_idir.y, l_inv_length * l_idir.z);
 
-    for (uint32_t mine = blockIdx.x * blockDim.x + threadIdx.x; mine < p.work.nitems; mine += gridDim.x * blockDim.x) {
-        const uint32_t x = mine % p.cam.width;
-        const uint32_t q = mine / p.cam.width;
-        const uint32_t r = q % p.cam.nrows;
-        const uint32_t s = p.cam.s_first + q / p.cam.nrows;
+    // Work: 8x8-pixel tiles, one per wave at a time, handed out by the launch's counter.  The lanes of a wave
+    // then look up voxels a few apart in two directions instead of 26 apart in one (a 64-pixel row segment of
+    // the 1080p frame spans 26 voxels of the 512^3 cloud and every lane pulled its own 64-byte line: 500 GB of
+    // fabric traffic for 50 GB of voxels), and a wave that draws cheap pixels simply draws again.
+    const int      lane = threadIdx.x & 63;
+    const uint32_t tiles_x = (p.cam.width + 7u) / 8u, tiles_y = (p.cam.nrows + 7u) / 8u;
+    const uint32_t tiles_per_sample = tiles_x * tiles_y, ntiles = tiles_per_sample * p.cam.s_count;
+    for (;;) {
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(p.work.counter, 1u);
+        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+        if (tile >= ntiles) break;
+        const uint32_t sl = tile / tiles_per_sample, tt = tile - sl * tiles_per_sample;
+        const uint32_t ty = tt / tiles_x, tx = tt - ty * tiles_x;
+        const uint32_t x = tx * 8u + ((uint32_t)lane & 7u), r = ty * 8u + ((uint32_t)lane >> 3);
+        if (x >= p.cam.width || r >= p.cam.nrows) continue;   // (no wave-level operation in the body below)
+        const uint32_t mine = (sl * p.cam.nrows + r) * p.cam.width + x;
+        const uint32_t s = p.cam.s_first + sl;
         const uint32_t ci = p.cam.x0 + x;
         const uint32_t cj = p.cam.y0 + p.cam.row_first + r * p.cam.row_stride;
         n_paths++;
