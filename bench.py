@@ -132,10 +132,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # VR_BENCH_REHEARSAL=1: every rank on GPU 0 and the exchange over gloo on host tensors — a way to walk the
+    # N > 1 path on a one-GPU box (RCCL refuses two ranks on one device); never a measurement
+    rehearsal = os.environ.get("VR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from volume_renderer_amd import MODE_EXACT, MODE_FAST, Backend, INTEGRATORS
     import scenes
@@ -163,11 +171,15 @@ def main():
         be.generate_cloud(n, scenes.cloud_radius(n))     # density resident in HBM before timing
 
     from volume_renderer_amd.scheduler import RowScheduler
-    sched = RowScheduler(H, W, dev, rank=rank, world=world)
+    sched = RowScheduler(H, W, torch.device("cpu") if rehearsal else dev, rank=rank, world=world)
+    staging = torch.zeros_like(sched.part, device=dev) if rehearsal else None
 
     def render_rows(first, stride, count, out):
-        be.render_row_set_device(opts, integ_id, first, stride, count, out.data_ptr())
+        target = staging if rehearsal else out
+        be.render_row_set_device(opts, integ_id, first, stride, count, target.data_ptr())
         be.synchronize()
+        if rehearsal:
+            out.copy_(staging)
 
     def step():
         return sched.render(render_rows)
@@ -196,8 +208,9 @@ def main():
         lookups += stats["ray_queries"] if mesh_scene else stats["density_lookups"]
     fence()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    agg = torch.tensor([float(lookups), float(kernel_ms), float(launches)], dtype=torch.float64, device=dev)
+    cdev = torch.device("cpu") if rehearsal else dev
+    tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    agg = torch.tensor([float(lookups), float(kernel_ms), float(launches)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
@@ -233,7 +246,8 @@ def main():
                 "workload": a.workload, "integrator": integ, "image": f"{W}x{H}", "spp": spp, "spp_at_1_gpu": spp_config,
                 "grid": (f"{n} mesh, threaded BVH" if mesh_scene else
                          f"{n}^3 procedural cloud (Perlin fbm), bricked 8^3, replicated per GPU"), "step_regime": regime,
-                "kernel_mode": a.mode, "partition": f"rows r::{world} per rank, RCCL all_gather" if world > 1 else "single GPU",
+                "kernel_mode": a.mode,
+                "partition": ("REHEARSAL: all ranks on one GPU, gloo" if rehearsal else f"rows r::{world} per rank, RCCL all_gather") if world > 1 else "single GPU",
                 "frame_mean_rgb": [float(x) for x in frame.mean(dim=(0, 1)).tolist()],
             },
             "glookups_per_s": lookups_all / max(kernel_ms_all / 1e3 / world, 1e-12) / 1e9,

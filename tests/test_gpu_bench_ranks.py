@@ -1,0 +1,40 @@
+"""bench.py with more than one rank, rehearsed on the one GPU of the test box: every rank on GPU 0, the exchange
+over gloo (VR_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device).  What is checked is the N > 1 plumbing —
+rendezvous, row sets, gather, max-over-ranks timing, the JSON line — not a rate."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(nranks, *args):
+    env = dict(os.environ, VR_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    if nranks == 1:
+        cmd = [sys.executable, "bench.py"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29600 + nranks), "bench.py"]
+    cmd += ["--gpus", str(nranks), "--steps", "1", "--warmup", "0", "--workload", "small", "--cpu-baseline", "off", *args]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE json line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_two_ranks_weak_and_strong():
+    one = run_bench(1, "--spp", "8")
+    weak = run_bench(2)                                # small is 4 spp: two ranks render 8
+    strong = run_bench(2, "--scaling", "strong", "--spp", "8")
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["spp"] == 8 and weak["config"]["spp_at_1_gpu"] == 4
+    assert strong["scaling"] == "strong" and strong["config"]["spp"] == 8
+    # the frame does not depend on how many ranks rendered it (streams keyed by absolute pixel and sample)
+    assert weak["config"]["frame_mean_rgb"] == one["config"]["frame_mean_rgb"] == strong["config"]["frame_mean_rgb"]
+    assert weak["lookups_per_sample"] == one["lookups_per_sample"]
+    for d in (one, weak, strong):
+        assert d["value"] > 0 and d["roofline"]["launches"] == d["n_gpus"]
