@@ -18,7 +18,8 @@
 // takes 10^4 steps), so the tracking kernel is persistent: a lane whose path has ended takes the next
 // item of its wave's chunk (one atomic on the global counter per chunk of 128 items) instead of idling
 // until the wave's longest path ends; items go out sub-sample by sub-sample, rows from the middle of
-// the frame outwards (see the refill).  The marchers take their items in slot order.
+// the frame outwards (see the refill).  The mesh marchers take their items in slot order, the grid
+// marchers as 8x8-pixel tiles from the same counter.
 #pragma once
 #include "vr_device.h"
 
@@ -117,7 +118,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 // ratio / delta tracking
 // =============================================================================================
 // Lane states.  The kernel alternates between a STEP LOOP, in which every walking lane runs the
-// same code (up to two iterations of the reference's while loop per trip, camera walk and shadow
+// same code (a few iterations of the reference's while loop per trip, camera walk and shadow
 // walk alike), and an EVENT PHASE, in which lanes that left the loop are served together: scatter
 // events start their shadow walk, finished shadow walks add the light and pick the new direction,
 // finished paths store their sample and take the next work item.  A lane that meets an event waits
@@ -204,7 +205,7 @@ vr_track_kernel(const TrackParams p)
     uint32_t rng_step = 0;                                 // iterations of the walk so far
     uint32_t xs0 = 1, xs1 = 0, xs2 = 0, xs3 = 0;           // the stream's xoshiro128+ state
     // density at iRay(tFar), fetched at the END of the previous trip so that its latency hides
-    // behind the loop overhead and the next trip's Philox block
+    // behind the loop overhead and the other waves of the SIMD
     float    cur_val = 0.0f;
     uint32_t cur_off = 0xffffffffu;     // its voxel offset (0xffffffff: outside the bbox)
     float    t_span = 0.0f;             // while t < t_span the walk is provably still inside that voxel
@@ -441,9 +442,9 @@ vr_track_kernel(const TrackParams p)
         if (!__any(st == ST_WALK)) break;   // every lane exhausted (events were all served above)
 
         // =========================== step loop ===========================
-        // One trip = up to TWO iterations of the reference's while loop.  Few lanes are in empty space at
+        // One trip = up to VR_TRIP_ITERS iterations of the reference's while loop.  Few lanes are in empty space at
         // any time but nearly every wave has one, so the empty-space code runs once per trip, after
-        // the two halves: a lane that finds sigma <= 0 sits out the rest of the trip and takes its
+        // the iterations: a lane that finds sigma <= 0 sits out the rest of the trip and takes its
         // run there.
         if (st == ST_WALK && rng_step > p.work.step_limit) { n_limit++; st = ST_FINISHED; }   // safety cap, once per round
 #pragma unroll 1
@@ -451,7 +452,7 @@ vr_track_kernel(const TrackParams p)
             bool empty = false;     // this lane's current iteration is an empty-space step, still to be taken
             bool parked = false;    // this lane has left its voxel and waits for the lookup at the end of the trip
 #pragma unroll
-            for (int half = 0; half < VR_TRIP_ITERS; ++half) {
+            for (int half = 0; half < VR_TRIP_ITERS; ++half) {   // (`half`: the trips once had two)
                 if (st != ST_WALK || empty || parked) continue;
                 const bool in_shadow = (INTEG == INTEG_RATIO) && shadow;
 
@@ -490,8 +491,8 @@ vr_track_kernel(const TrackParams p)
                 }
                 t += len;                                                                     // :88 / :255
                 rng_step += 1;
-                // the second iteration's voxel.  With sub-voxel steps (use_span) few lanes need one,
-                // yet nearly every wave has such a lane: it sits out the second half instead and
+                // the next iteration's voxel.  With sub-voxel steps (SPAN) few lanes need one,
+                // yet nearly every wave has such a lane: it sits out the rest of the trip instead and
                 // is served by the lookup at the end of the trip.
                 if (half + 1 < VR_TRIP_ITERS && t <= t1) {
                     if (SPAN) parked = !(t < t_span);
