@@ -579,7 +579,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             b->passes.push_back(p);
         }
         Pass& ev = b->passes[b->passes_used++];
-        HIP_TRY(b, hipMemsetAsync(b->d_work, 0, sizeof(uint32_t), b->stream));
+        HIP_TRY(b, hipMemsetAsync(b->d_work, 0, 256, b->stream));   // the item counter (grid marchers: one per strip, 32 B apart)
 
         if (integrator == VR_INTEGRATOR_NANOVDB_SIMPLE || integrator == VR_INTEGRATOR_NANOVDB_EMISSION) {
             GridMarchParams p{};

@@ -928,14 +928,31 @@ __global__ void __launch_bounds__(256) vr_gridmarch_kernel(const GridMarchParams
     // fabric traffic for 50 GB of voxels), and a wave that draws cheap pixels simply draws again.
     const int      lane = threadIdx.x & 63;
     const uint32_t tiles_x = (p.cam.width + 7u) / 8u, tiles_y = (p.cam.nrows + 7u) / 8u;
-    const uint32_t tiles_per_sample = tiles_x * tiles_y, ntiles = tiles_per_sample * p.cam.s_count;
+    // Tile order.  The light marches of vertically adjacent tiles run through the same voxel columns, and so
+    // do the sub-samples of one tile; tiles drawn one after the other are rendered at the same time.  So the
+    // frame is cut into 8 vertical strips, one per XCD (workgroups go round-robin over the XCDs, each with an
+    // L2 of its own), and a strip goes out column by column, within a column sample by sample, rows innermost.
+    // A wave whose strip is used up helps with the next one.
+    const uint32_t column_tiles = tiles_y * p.cam.s_count;
+#ifndef VR_GM_STRIPS
+#define VR_GM_STRIPS 8
+#endif
+    uint32_t strip_try = 0;
+    const uint32_t xcd = VR_GM_STRIPS > 1 ? (blockIdx.x & 7u) : 0u;
     for (;;) {
-        uint32_t tile = 0;
-        if (lane == 0) tile = atomicAdd(p.work.counter, 1u);
-        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-        if (tile >= ntiles) break;
-        const uint32_t sl = tile / tiles_per_sample, tt = tile - sl * tiles_per_sample;
-        const uint32_t ty = tt / tiles_x, tx = tt - ty * tiles_x;
+        uint32_t tile = 0, c_lo = 0, c_hi = 0;
+        bool     got = false;
+        while (strip_try < VR_GM_STRIPS) {
+            const uint32_t strip = (xcd + strip_try) % VR_GM_STRIPS;
+            c_lo = tiles_x * strip / VR_GM_STRIPS; c_hi = tiles_x * (strip + 1u) / VR_GM_STRIPS;
+            if (lane == 0) tile = atomicAdd(p.work.counter + strip * 8u, 1u);
+            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+            if (tile < (c_hi - c_lo) * column_tiles) { got = true; break; }
+            strip_try++;
+        }
+        if (!got) break;
+        const uint32_t tx = c_lo + tile / column_tiles, rem = tile % column_tiles;
+        const uint32_t sl = rem / tiles_y, ty = rem - sl * tiles_y;
         const uint32_t x = tx * 8u + ((uint32_t)lane & 7u), r = ty * 8u + ((uint32_t)lane >> 3);
         if (x >= p.cam.width || r >= p.cam.nrows) continue;   // (no wave-level operation in the body below)
         const uint32_t mine = (sl * p.cam.nrows + r) * p.cam.width + x;
