@@ -455,6 +455,12 @@ def test_errors_are_reported_not_thrown(backend, cloud64):
         with pytest.raises(BackendError) as e:
             b2.render(copy_options(o, stepSizeMin=0.0), RATIO)   # the reference would never terminate
         assert e.value.code == -1
+        with pytest.raises(BackendError) as e:
+            b2.render(copy_options(o, rayPerPixelCount=(1 << 20) + 1), RATIO)   # the stream id keeps 20 bits of the sample index
+        assert e.value.code == -1 and "rayPerPixelCount" in str(e.value)
+        with pytest.raises(BackendError) as e:
+            b2.render(copy_options(o, maxDepth=256), RATIO)           # uint8_t in the reference; the bounce has 8 bits
+        assert e.value.code == -1
         with pytest.raises(BackendError):
             b2.render(o, 7)
     finally:

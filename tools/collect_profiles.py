@@ -39,7 +39,10 @@ def counters(path, kernel="vr_track_kernel"):
 
 ks = newest("prof_kt/*/*kernel_stats.csv")
 shutil.copy(ks, os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
-shutil.copy(os.path.join(G, "bench_default.log"), os.path.join(P, f"{tag}_bench.json"))
+with open(os.path.join(G, "bench_default.log")) as f:      # the log holds stderr noise too: keep the JSON line
+    line = [l for l in f.read().splitlines() if l.startswith("{")][-1]
+with open(os.path.join(P, f"{tag}_bench.json"), "w") as f:
+    f.write(line + "\n")
 out = {}
 for name in ("prof_fetch", "prof_write", "prof_sq"):
     f = newest(f"{name}/*/*counter_collection.csv")
