@@ -369,10 +369,17 @@ void set_map(vr_backend* b, const float* inv_mat, const float* vec, const float*
 // ---- threaded BVH (replaces the Embree scene, SceneLoader.cpp:150-199) ----
 struct BuildTri { float lo[3], hi[3], c[3]; uint32_t prim; };
 
-void build_bvh(std::vector<BuildTri>& t, uint32_t first, uint32_t count, std::vector<BvhNode>& nodes, std::vector<uint32_t>& order)
+// The tree is built once (median split on the longest centroid axis, leaves of <= 4 triangles) and laid out
+// eight times, once per sign octant of the ray direction: a threaded BVH visits children in array order, so
+// each octant gets the order in which ITS rays meet the nearer child first and the far one can be culled
+// against the hit already found.
+struct TreeNode { BvhNode box; int axis; uint32_t left, right; };
+
+uint32_t build_bvh(std::vector<BuildTri>& t, uint32_t first, uint32_t count, std::vector<TreeNode>& tree, std::vector<uint32_t>& order)
 {
-    BvhNode nd{};
-    float   clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    TreeNode tn{};
+    BvhNode& nd = tn.box;
+    float    clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (int a = 0; a < 3; ++a) { nd.lo[a] = INFINITY; nd.hi[a] = -INFINITY; }
     for (uint32_t i = first; i < first + count; ++i)
         for (int a = 0; a < 3; ++a) {
@@ -386,23 +393,38 @@ void build_bvh(std::vector<BuildTri>& t, uint32_t first, uint32_t count, std::ve
         const float pad = 1e-4f * std::max(ext, 1e-3f) + 1e-5f * mag;
         nd.lo[a] -= pad; nd.hi[a] += pad;
     }
-    const uint32_t me = (uint32_t)nodes.size();
-    nodes.push_back(nd);
+    const uint32_t me = (uint32_t)tree.size();
+    tree.push_back(tn);
     int axis = 0;
     for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
     if (count <= 4 || !(chi[axis] > clo[axis])) {
-        nodes[me].first = (uint32_t)order.size();
-        nodes[me].count = count;
+        tree[me].box.first = (uint32_t)order.size();
+        tree[me].box.count = count;
         for (uint32_t i = first; i < first + count; ++i) order.push_back(i);
     } else {
         const uint32_t mid = count / 2;
         std::nth_element(t.begin() + first, t.begin() + first + mid, t.begin() + first + count,
                          [axis](const BuildTri& x, const BuildTri& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.prim < y.prim); });
-        nodes[me].first = 0; nodes[me].count = 0;
-        build_bvh(t, first, mid, nodes, order);
-        build_bvh(t, first + mid, count - mid, nodes, order);
+        tree[me].box.first = 0; tree[me].box.count = 0;
+        tree[me].axis = axis;
+        const uint32_t l = build_bvh(t, first, mid, tree, order);             // lower centroids along `axis`
+        const uint32_t r = build_bvh(t, first + mid, count - mid, tree, order);
+        tree[me].left = l; tree[me].right = r;
     }
-    nodes[me].skip = (uint32_t)nodes.size();
+    return me;
+}
+
+// depth-first layout for the rays of one sign octant (bit a set: direction component a is negative)
+void thread_bvh(const std::vector<TreeNode>& tree, uint32_t n, int octant, std::vector<BvhNode>& nodes, size_t base)
+{
+    const size_t me = nodes.size();
+    nodes.push_back(tree[n].box);
+    if (tree[n].box.count == 0) {
+        const bool neg = (octant >> tree[n].axis) & 1;
+        thread_bvh(tree, neg ? tree[n].right : tree[n].left, octant, nodes, base);
+        thread_bvh(tree, neg ? tree[n].left : tree[n].right, octant, nodes, base);
+    }
+    nodes[me].skip = (uint32_t)(nodes.size() - base);
 }
 
 struct Frame {
@@ -905,9 +927,11 @@ int vr_backend_set_mesh(vr_backend* b, const vr_mesh_desc* m)
         }
         bt[t].prim = t;
     }
-    std::vector<BvhNode>  nodes;
+    std::vector<TreeNode> tree;
     std::vector<uint32_t> order;
-    build_bvh(bt, 0, m->ntris, nodes, order);
+    build_bvh(bt, 0, m->ntris, tree, order);
+    std::vector<BvhNode>  nodes;                         // 8 layouts of tree.size() nodes each
+    for (int octant = 0; octant < 8; ++octant) thread_bvh(tree, 0, octant, nodes, nodes.size());
     std::vector<TriDev> tris(order.size());
     for (size_t k = 0; k < order.size(); ++k) {
         const uint32_t  prim = bt[order[k]].prim;
@@ -931,7 +955,7 @@ int vr_backend_set_mesh(vr_backend* b, const vr_mesh_desc* m)
         HIP_TRY(b, hipMalloc((void**)&b->d_diffuse, (size_t)m->nshapes * 3 * sizeof(float)));
         HIP_TRY(b, hipMemcpy(b->d_diffuse, m->shape_diffuse, (size_t)m->nshapes * 3 * sizeof(float), hipMemcpyHostToDevice));
     }
-    b->nnodes = (uint32_t)nodes.size(); b->nshapes = m->nshapes;
+    b->nnodes = (uint32_t)tree.size(); b->nshapes = m->nshapes;
     b->has_mesh = true;
     return VR_OK;
 }

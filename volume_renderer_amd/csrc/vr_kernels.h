@@ -622,7 +622,9 @@ vr_track_kernel(const TrackParams p)
 // =============================================================================================
 
 // Threaded BVH in depth-first order: a node that is hit continues at node+1 (its first child, or
-// for a leaf the next subtree), a node that is missed continues at `skip`.  No stack.
+// for a leaf the next subtree), a node that is missed continues at `skip`.  No stack.  MeshDev::nodes
+// holds eight such layouts of the same tree, one per sign octant of the ray direction, each visiting
+// the child nearer to its rays first.
 struct BvhNode {
     float    lo[3], hi[3];
     uint32_t skip;
@@ -680,8 +682,9 @@ __device__ __forceinline__ int closest_hit(const MeshDev& m, f3 org, f3 dir, flo
     float    best_t = __builtin_huge_valf();
     uint32_t best_prim = 0xffffffffu;
     uint32_t n = 0;
+    const BvhNode* nodes = m.nodes + ((dir.x < 0.0f ? 1u : 0u) | (dir.y < 0.0f ? 2u : 0u) | (dir.z < 0.0f ? 4u : 0u)) * m.nnodes;
     while (n < m.nnodes) {
-        const BvhNode nd = m.nodes[n];
+        const BvhNode nd = nodes[n];
         // slab test; fminf/fmaxf drop NaNs (0 * inf), which keeps the test conservative
         float ax = (nd.lo[0] - org.x) * ix, bx = (nd.hi[0] - org.x) * ix;
         float ay = (nd.lo[1] - org.y) * iy, by = (nd.hi[1] - org.y) * iy;
