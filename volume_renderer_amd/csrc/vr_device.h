@@ -214,11 +214,20 @@ __device__ __forceinline__ uint32_t empty_run(float& t, float t_safe, float step
     return k + 1;
 }
 
+// (int32_t)floorf(x) in one instruction (v_cvt_flr_i32_f32; the compiler emits v_floor + v_cvt_i32).  Same
+// result wherever the floor fits an int32, and coordinates are clipped to the bbox long before that.
+__device__ __forceinline__ int32_t floor_to_int(float x)
+{
+    int32_t r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ float grid_value_nocache(const GridDev& g, f3 p)
 {
-    int32_t i = (int32_t)floorf(p.x) - g.min[0];
-    int32_t j = (int32_t)floorf(p.y) - g.min[1];
-    int32_t k = (int32_t)floorf(p.z) - g.min[2];
+    int32_t i = floor_to_int(p.x) - g.min[0];
+    int32_t j = floor_to_int(p.y) - g.min[1];
+    int32_t k = floor_to_int(p.z) - g.min[2];
     if ((uint32_t)i >= (uint32_t)g.dim[0] || (uint32_t)j >= (uint32_t)g.dim[1] || (uint32_t)k >= (uint32_t)g.dim[2])
         return g.background;
     return g.bricks[brick_offset(g, (uint32_t)i, (uint32_t)j, (uint32_t)k)];

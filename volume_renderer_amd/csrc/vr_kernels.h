@@ -1005,7 +1005,10 @@ __global__ void __launch_bounds__(256) vr_gridmarch_kernel(const GridMarchParams
                         const float light_step_size = step_size * 20.0f;            // :52
                         const float num_steps_light = ceilf(l1 / light_step_size);  // :53 (t1, not t1 - t0)
                         for (uint32_t nl = 0; (float)nl < num_steps_light; ++nl) {  // :55
-                            const float t_light = (float)((double)light_step_size * ((double)nl + 0.5));   // :56
+                            // light_step_size * (nl + 0.5) in double, then float (:56): 10 nl + 5, an integer below 2^24,
+                            // so the integer form is the same number without four fp64 instructions per step
+                            const float t_light = nl < (1u << 20) ? (float)(10u * nl + 5u)
+                                                                  : (float)((double)light_step_size * ((double)nl + 0.5));
                             tau += grid_value_nocache(p.density, ray_at(leye, l_dir, l0 + t_light)) * light_ray_density;   // :57
                             n_lookups++;
                         }
