@@ -51,6 +51,9 @@ struct Math<true> {
     static __device__ __forceinline__ float exp_(float x) { return vrm_expf(x); }
     static __device__ __forceinline__ void sincos_(float x, float& s, float& c) { vrm_sincosf(x, s, c); }
     static __device__ __forceinline__ float div_(float a, float b) { return a / b; }
+    static __device__ __forceinline__ float rcp_(float x) { return 1 / x; }
+    static __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
+    static __device__ __forceinline__ f3 normalize_(f3 v) { return normalize3(v); }
 };
 template <>
 struct Math<false> {
@@ -60,6 +63,16 @@ struct Math<false> {
     static __device__ __forceinline__ float exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
     static __device__ __forceinline__ void sincos_(float x, float& s, float& c) { s = __sinf(x); c = __cosf(x); }
     static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+    // the event phases' divisions, square roots and normalisations: correctly rounded they are 10-15
+    // instructions each and a third of an event phase; one-ulp hardware forms in the production mode
+    static __device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ f3 normalize_(f3 v)
+    {
+        const float mag2 = v.x * v.x + v.y * v.y + v.z * v.z;
+        const float inv = mag2 > 0 ? __builtin_amdgcn_rsqf(mag2) : 1.0f;
+        return mk3(v.x * inv, v.y * inv, v.z * inv);
+    }
 };
 
 // ---- random numbers: Philox4x32-10 keys the streams, xoshiro128+ runs them --------------------
@@ -136,11 +149,12 @@ __device__ __forceinline__ f3 mat_mult(const float* m, f3 p)                    
 }
 // Ray::clip(CoordBBox): slab test against [min, max+1], same comparisons, so NaNs from 0*inf
 // behave as in the reference                                                                   Ray.h:397-423,512-520
+template <bool EXACT = true>
 __device__ __forceinline__ bool ray_clip(f3 eye, f3 dir, float& t0, float& t1, const float* bmin, const float* bmax1)
 {
     // mInvDir(1/dir)                                                                            Ray.h:69
     const float e[3] = { eye.x, eye.y, eye.z };
-    const float inv[3] = { 1 / dir.x, 1 / dir.y, 1 / dir.z };
+    const float inv[3] = { Math<EXACT>::rcp_(dir.x), Math<EXACT>::rcp_(dir.y), Math<EXACT>::rcp_(dir.z) };
     float a0 = t0, a1 = t1;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -280,9 +294,11 @@ __device__ __forceinline__ float perlin_eval_density(f3 p)
 
 // ---- phase function and direction sampling -----------------------------------------------------
 // PhaseFunction::henyey_greenstein                                                              PhaseFunction.cpp:4-8
+template <bool EXACT = true>
 __device__ __forceinline__ float hg_phase(float g, float cos_theta)
 {
     float denom = 1 + g * g - 2 * g * cos_theta;
+    if (!EXACT) return (0.07957747154594767f * (1 - g * g)) * __builtin_amdgcn_rcpf(denom * __builtin_amdgcn_sqrtf(denom));
     return (float)(1 / (4 * VR_PI_D) * (1 - g * g) / (denom * sqrtf(denom)));
 }
 // DirectionSampler::sampleHenyeyGreenstein + ONB::Update                       DirectionSampler.cpp:38-72, ONB.cpp:5-22
@@ -292,19 +308,19 @@ __device__ __forceinline__ f3 hg_sample(float g, f3 direction, float xi, float x
     f3 n = direction, s;
     if (fabsf(n.x) > fabsf(n.z)) { s.x = -n.y; s.y = n.x; s.z = 0; }
     else                         { s.x = 0; s.y = -n.z; s.z = n.y; }
-    s = normalize3(s);
+    s = Math<EXACT>::normalize_(s);
     f3 t = cross3(n, s);
-    f3 nd = normalize3(direction);
+    f3 nd = Math<EXACT>::normalize_(direction);
     float cos_theta;
     if (g != 0.0f) {
-        float aux = ((1 - g * g) / (1 - g + 2 * g * xi));
-        cos_theta = (1 + g * g - (aux * aux)) / (2 * g);
+        float aux = Math<EXACT>::div_((1 - g * g), (1 - g + 2 * g * xi));
+        cos_theta = Math<EXACT>::div_((1 + g * g - (aux * aux)), (2 * g));
     } else {
         cos_theta = (float)(1.0 - 2.0 * (double)xi);
     }
     float c2 = 1.0f - cos_theta * cos_theta;
-    float sin_theta = sqrtf((0.0f < c2) ? c2 : 0.0f);
-    float phi = (float)((double)(xi2 * 2) * VR_PI_D);
+    float sin_theta = Math<EXACT>::sqrt_((0.0f < c2) ? c2 : 0.0f);
+    float phi = EXACT ? (float)((double)(xi2 * 2) * VR_PI_D) : xi2 * 6.283185307179586f;
     float sp, cp;
     Math<EXACT>::sincos_(phi, sp, cp);
     f3 v1 = scale3(s, sin_theta * cp);

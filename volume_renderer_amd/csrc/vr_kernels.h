@@ -297,7 +297,7 @@ vr_track_kernel(const TrackParams p)
                 n_lookups += rng_step;
                 rng_ts |= 0x80000000u; rng_step = 0;
                 float c0 = 1e-5f, c1 = VR_FLT_MAX;
-                if (!ray_clip(so, light, c0, c1, c->bmin, c->bmax1)) {            // :229-232
+                if (!ray_clip<EXACT>(so, light, c0, c1, c->bmin, c->bmax1)) {     // :229-232
                     Tsh = 1.0f; st = ST_SHADOW_DONE;
                 } else {
                     shadow = true; Tsh = 1.0f; st = ST_WALK;
@@ -314,7 +314,7 @@ vr_track_kernel(const TrackParams p)
                     rng_ts &= 0x7fffffffu;    // back on the camera walk
                     const f3 light = mk3(c->light[0], c->light[1], c->light[2]);
                     const float cos_theta = dot3(wdir, light);                            // :144
-                    const float hg = hg_phase(c->g, cos_theta);                           // :145
+                    const float hg = hg_phase<EXACT>(c->g, cos_theta);                    // :145
                     f3 nee = scale3(mk3(c->light_color[0], c->light_color[1], c->light_color[2]), T * Tsh); // :147-152
                     nee = scale3(nee, scatter_len);
                     nee = scale3(nee, hg);
@@ -340,12 +340,12 @@ vr_track_kernel(const TrackParams p)
                         const f3 primary = primary_direction(c->cam, c->cam.x0 + x, c->cam.y0 + c->cam.row_first + r * c->cam.row_stride, s);
                         cos_pdf = dot3(normalize3(primary), wdir);
                     }
-                    pdf *= hg_phase(c->g, cos_pdf);
+                    pdf *= hg_phase<EXACT>(c->g, cos_pdf);
                 }
                 wdir = scattered;                                                         // :178
                 shadow = false;
                 float c0 = 1e-5f, c1 = VR_FLT_MAX;
-                if (!ray_clip(scatter_p, scattered, c0, c1, c->bmin, c->bmax1)) {         // :182-187 "scattering failed"
+                if (!ray_clip<EXACT>(scatter_p, scattered, c0, c1, c->bmin, c->bmax1)) {  // :182-187 "scattering failed"
                     st = ST_FINISHED;
                 } else if (depth_remaining <= 0) {
                     // `while (... && depthRemaining > 0)`: out of scatter budget, the walk ends as
@@ -418,11 +418,11 @@ vr_track_kernel(const TrackParams p)
                     // wRay.worldToIndexF(grid)               Ray.h:257-267, NanoVDB.h:2262-2270
                     const f3 ieye = mat_mult(c->inv_mat, mk3(weye.x - c->vec[0], weye.y - c->vec[1], weye.z - c->vec[2]));
                     const f3 idir = mat_mult(c->inv_mat, wdir);
-                    const float length = sqrtf(idir.x * idir.x + idir.y * idir.y + idir.z * idir.z);
-                    const float inv_length = 1.0f / length;
+                    const float length = M::sqrt_(idir.x * idir.x + idir.y * idir.y + idir.z * idir.z);
+                    const float inv_length = M::rcp_(length);
                     const f3 ndir = mk3(inv_length * idir.x, inv_length * idir.y, inv_length * idir.z);
                     float c0 = length * 1e-5f, c1 = VR_FLT_MAX;
-                    if (!ray_clip(ieye, ndir, c0, c1, c->bmin, c->bmax1) || c->max_depth == 0) {
+                    if (!ray_clip<EXACT>(ieye, ndir, c0, c1, c->bmin, c->bmax1) || c->max_depth == 0) {
                         // missed the grid (:37-39), or a zero scatter budget: the loop never runs (:55, :208)
                         store_sample(p.work.samples, item, mk3(c->background[0], c->background[1], c->background[2]));
                     } else {
