@@ -82,11 +82,20 @@ struct TrackParams {
 };
 
 // primary ray of (abs column i, abs row j, sub-sample s)                  BaseIntegrator.cpp:35-64
+// EXACT: the reference's arithmetic (x and y in double, correctly rounded normalisation); otherwise the same
+// formula in float with a hardware reciprocal square root — one ulp on a direction, for the FAST trackers only
+template <bool EXACT = true>
 __device__ __forceinline__ f3 primary_direction(const CameraDev& c, uint32_t i, uint32_t j, uint32_t s)
 {
-    float x = (float)((2 * ((int)i + 0.5) / (float)c.ref_w - 1) * c.aspect * c.scale);
-    float y = (float)((1 - 2 * ((int)j + 0.5) / (float)c.ref_h) * c.scale);
-    f3 dn = normalize3(mk3(x, y, -1));
+    float x, y;
+    if (EXACT) {
+        x = (float)((2 * ((int)i + 0.5) / (float)c.ref_w - 1) * c.aspect * c.scale);
+        y = (float)((1 - 2 * ((int)j + 0.5) / (float)c.ref_h) * c.scale);
+    } else {
+        x = ((2.0f * ((float)i + 0.5f)) * __builtin_amdgcn_rcpf((float)c.ref_w) - 1.0f) * c.aspect * c.scale;
+        y = (1.0f - (2.0f * ((float)j + 0.5f)) * __builtin_amdgcn_rcpf((float)c.ref_h)) * c.scale;
+    }
+    f3 dn = Math<EXACT>::normalize_(mk3(x, y, -1));
     float2 off = c.offsets[s];
     f3 d = mk3(dn.x + off.x * c.pixel_w, dn.y + off.y * c.pixel_h, dn.z + 0.0f);
     if (c.has_rot) {
@@ -337,8 +346,8 @@ vr_track_kernel(const TrackParams p)
                         // the delta tracker takes the angle to the normalised PRIMARY direction (:22, :139)
                         const uint32_t x = item % c->cam.width, q = item / c->cam.width;
                         const uint32_t r = q % c->cam.nrows, s = c->cam.s_first + q / c->cam.nrows;
-                        const f3 primary = primary_direction(c->cam, c->cam.x0 + x, c->cam.y0 + c->cam.row_first + r * c->cam.row_stride, s);
-                        cos_pdf = dot3(normalize3(primary), wdir);
+                        const f3 primary = primary_direction<EXACT>(c->cam, c->cam.x0 + x, c->cam.y0 + c->cam.row_first + r * c->cam.row_stride, s);
+                        cos_pdf = dot3(M::normalize_(primary), wdir);
                     }
                     pdf *= hg_phase<EXACT>(c->g, cos_pdf);
                 }
@@ -413,7 +422,7 @@ vr_track_kernel(const TrackParams p)
                     const uint32_t cj = c->cam.y0 + c->cam.row_first + r * c->cam.row_stride;
                     n_paths++;
                     // castRay prologue                      IntegratorRatioTracking.cpp:13-53
-                    wdir = primary_direction(c->cam, ci, cj, s);
+                    wdir = primary_direction<EXACT>(c->cam, ci, cj, s);
                     const f3 weye = mk3(c->cam.pos[0], c->cam.pos[1], c->cam.pos[2]);
                     // wRay.worldToIndexF(grid)               Ray.h:257-267, NanoVDB.h:2262-2270
                     const f3 ieye = mat_mult(c->inv_mat, mk3(weye.x - c->vec[0], weye.y - c->vec[1], weye.z - c->vec[2]));
