@@ -1,8 +1,13 @@
 #!/bin/bash
-# sweep of one env tunable over the mesh workloads, same box
-for w in "config5_marcher_sphere_4k 16" "config5_marcher_nee_sphere_4k 16"; do
-  read WL SPP <<< "$w"
-  for v in 4 1 2 3 6 8 4; do
-    VR_TUNE_BVH_LEAF=$v timeout -k 10 120 python -u bench.py --workload $WL --spp $SPP --steps 2 --warmup 1 --cpu-baseline off 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$WL leaf $v', round(d['ms_per_step'],2), 'ms', d['config']['frame_mean_rgb'][0])" || exit 1
+# sweep of the round's event threshold per regime, same box, one process per point (0 = built-in default)
+sweep() {
+  read WL SPP <<< "$1"; shift
+  for v in "$@"; do
+    if [ $v = 0 ]; then unset VR_TUNE_ROUND_EVENTS; else export VR_TUNE_ROUND_EVENTS=$v; fi
+    timeout -k 10 120 python -u bench.py --workload $WL --spp $SPP --steps 2 --warmup 1 --cpu-baseline off 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$WL events $v', round(d['ms_per_step'],1), 'ms lanes', round(d['divergence']['walking_lanes_per_trip'],1), d['divergence']['event_phases'])" || exit 1
   done
-done
+}
+sweep "config2_ratio_1080p_64spp_cloud512 64" 0 10 12 14 20 0
+sweep "config3_delta_1080p_256spp_cloud512 64" 0 8 10 14 16 0
+sweep "config2_textbook 64" 0 16 20 28 0
+sweep "config3_textbook 256" 0 16 20 28 0
