@@ -29,8 +29,9 @@ enum {
      * oracle/vr_oracle.c in VRO_MATH_SHARED + VRO_RNG_PHILOX mode.  The parity mode. */
     VR_MODE_EXACT = 0,
     /* Same algorithm and random streams, hardware transcendentals (v_log_f32, v_exp_f32,
-     * v_sin_f32, v_cos_f32) and empty-space stepping batched over cubes of empty voxels: differs
-     * from EXACT only by rounding.  The production mode. */
+     * v_sin_f32, v_cos_f32; in the trackers also v_rcp / v_sqrt / v_rsq where EXACT divides and
+     * takes roots correctly rounded) and empty-space stepping batched over cubes of empty voxels:
+     * differs from EXACT only by rounding.  The production mode. */
     VR_MODE_FAST = 1,
     /* EXACT arithmetic with FAST's batched empty-space stepping: must also be bit-identical to
      * the oracle; exists so that tests can pin the batching on its own. */
