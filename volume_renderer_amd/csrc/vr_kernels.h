@@ -161,6 +161,16 @@ __device__ __forceinline__ const T* opaque(const T* p)
     return (const T*)v;
 }
 
+// Lane state that only the event phases (and the rare scatter / absorption branches of the step loop) touch
+// lives in LDS, one dword per lane and variable: 15 of the ~110 registers the state would need, which is what
+// lets the step loop keep the rest in 96.  These proxies make such a variable read and assign like a local.
+struct LdsF3 {
+    float* p;   // this lane's x; y and z follow at strides of 256 lanes
+    __device__ __forceinline__ operator f3() const { return mk3(p[0], p[256], p[512]); }
+    __device__ __forceinline__ LdsF3& operator=(f3 v) { p[0] = v.x; p[256] = v.y; p[512] = v.z; return *this; }
+    __device__ __forceinline__ LdsF3& operator=(const LdsF3& o) { return *this = (f3)o; }
+};
+
 // Waves per SIMD the register allocator must allow.  Left alone the FAST kernels use 98-112 VGPRs
 // (4 waves); held to 96 (5 waves, the ratio tracker then spills 32 bytes) they are 8 % faster.
 #ifndef VR_TRACK_WAVES
@@ -192,25 +202,29 @@ vr_track_kernel(const TrackParams p)
     // ---- per-lane path state (HandleIntersectionData, BaseIntegrator.h:21-50) ----
     uint32_t st = ST_NEED;
     bool     shadow = false;            // walking directLightningRayMarch
-    uint32_t item = 0;
+    __shared__ float s_cold[15][256];
+    float* const cold_lane = &s_cold[0][threadIdx.x];
+    uint32_t& item = *(uint32_t*)(cold_lane + 11 * 256);
     f3       eye = mk3(0, 0, 0), dir = mk3(0, 0, 1);   // current index-space ray (camera walk or shadow walk)
     // voxel-span / empty-run estimates only: 1/dir (NaN where dir == 0: fminf then ignores that axis)
     // and, per axis, (dir > 0 ? 1 - slack : slack) - eye, so that the ray leaves the shrunk voxel
     // whose corner is f at t = (f + span_off) * inv
     f3       inv = mk3(0, 0, 1), span_off = mk3(0, 0, 0);
-    float    t = 0, t1 = 0, t0 = 0;     // tFar, iRay.t1(), iRay.t0()
-    f3       wdir = mk3(0, 0, 1);       // data->rayDirection
-    f3       radiance = mk3(0, 0, 0);   // data->radiance / result
+    float    t = 0, t1 = 0;             // tFar, iRay.t1()
+    float&   t0 = cold_lane[10 * 256];  // iRay.t0()
+    LdsF3    wdir{cold_lane};           // data->rayDirection
+    LdsF3    radiance{cold_lane + 3 * 256};   // data->radiance / result
     // data->transmission, shadow-walk transmission.  (Tsh and t0 are never alive together, but sharing one
     // register between them measured 2 % slower: the allocator's choices elsewhere changed.)
     float    T = 1.0f, Tsh = 1.0f;
     float    pdf = 1.0f;                // data->rayPDF (only read with useImportanceSampling)
-    int      depth_remaining = 0;
-    f3       scatter_p = mk3(0, 0, 0);  // iRay(tFar) of the pending scatter event
-    float    scatter_len = 0;           // its pathLength (ST_ABSORBED: mu_a of the absorbing step)
+    int&     depth_remaining = *(int*)(cold_lane + 14 * 256);
+    LdsF3    scatter_p{cold_lane + 6 * 256};   // iRay(tFar) of the pending scatter event
+    float&   scatter_len = cold_lane[9 * 256]; // its pathLength (ST_ABSORBED: mu_a of the absorbing step)
     // names the walk's stream (vr_device.h): pixel, and in one word sample (bits 0-19), bounce (20-27)
     // and the shadow-walk flag (bit 31)
-    uint32_t rng_pixel = 0, rng_ts = 0;
+    uint32_t& rng_pixel = *(uint32_t*)(cold_lane + 12 * 256);
+    uint32_t& rng_ts = *(uint32_t*)(cold_lane + 13 * 256);
     uint32_t rng_step = 0;                                 // iterations of the walk so far
     uint32_t xs0 = 1, xs1 = 0, xs2 = 0, xs3 = 0;           // the stream's xoshiro128+ state
     // density at iRay(tFar), fetched at the END of the previous trip so that its latency hides
@@ -374,7 +388,8 @@ vr_track_kernel(const TrackParams p)
             if (IS) {
                 // color += rayResults[i] / std::max(0.1f, rayPDFs[i])                     BaseIntegrator.cpp:78
                 const float den = (0.1f < pdf) ? pdf : 0.1f;
-                radiance = mk3(radiance.x / den, radiance.y / den, radiance.z / den);
+                const f3 r = radiance;
+                radiance = mk3(r.x / den, r.y / den, r.z / den);
             }
             store_sample(p.work.samples, item, radiance);
             st = ST_NEED;
