@@ -171,11 +171,26 @@ struct LdsF3 {
     __device__ __forceinline__ LdsF3& operator=(const LdsF3& o) { return *this = (f3)o; }
 };
 
-// Waves per SIMD the register allocator must allow.  Left alone the FAST kernels use 98-112 VGPRs
-// (4 waves); held to 96 (5 waves, the ratio tracker then spills 32 bytes) they are 8 % faster.
+// The ray's geometry (origin, direction, and the two vectors of the voxel-span estimate) is read once per trip,
+// by the lookup: with it in LDS as well a FAST kernel needs 73-80 registers and six waves fit a SIMD (26 KB of
+// LDS per block, six blocks per CU).  Measured against five waves with the geometry in registers: +7 % where
+// trips are long (sub-voxel steps) and for the ratio tracker, -4 % for the delta tracker with voxel-sized
+// steps, which looks a voxel up in every iteration and keeps its geometry in registers.
+#define VR_GEO_IN_LDS(INTEG, EXACT, SPAN) (!(EXACT) && ((SPAN) || (INTEG) == INTEG_RATIO))
+// Waves per SIMD the register allocator must allow (EXACT kernels: 98-123 VGPRs, four waves).
 #ifndef VR_TRACK_WAVES
-#define VR_TRACK_WAVES(INTEG, EXACT) (!(EXACT) ? 5 : 4)
+#define VR_TRACK_WAVES(INTEG, EXACT, SPAN) ((EXACT) ? 4 : (VR_GEO_IN_LDS(INTEG, EXACT, SPAN) ? 6 : 5))
 #endif
+template <bool IN_LDS>
+struct GeoVec {
+    typedef LdsF3 type;
+    static __device__ __forceinline__ LdsF3 make(float* lane_slot) { return LdsF3{lane_slot}; }
+};
+template <>
+struct GeoVec<false> {
+    typedef f3 type;
+    static __device__ __forceinline__ f3 make(float*) { return mk3(0, 0, 1); }
+};
 
 // SKIP: take runs of empty-space iterations at once (empty_run, vr_device.h) — same results bit
 // for bit, fewer trips through the loop.
@@ -185,7 +200,7 @@ struct LdsF3 {
 // remember the voxel's t-interval.  Compile-time too: as run-time flags in the step loop they cost
 // 2.5 % and 6.5 %.
 template <int INTEG, bool EXACT, bool SKIP, bool IS, bool TEMP, bool SPAN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VR_TRACK_WAVES(INTEG, EXACT), VR_TRACK_WAVES(INTEG, EXACT))))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VR_TRACK_WAVES(INTEG, EXACT, SPAN), VR_TRACK_WAVES(INTEG, EXACT, SPAN))))
 vr_track_kernel(const TrackParams p)
 {
     typedef Math<EXACT> M;
@@ -202,23 +217,25 @@ vr_track_kernel(const TrackParams p)
     // ---- per-lane path state (HandleIntersectionData, BaseIntegrator.h:21-50) ----
     uint32_t st = ST_NEED;
     bool     shadow = false;            // walking directLightningRayMarch
-    __shared__ float s_cold[15][256];
+    __shared__ float s_cold[26][256];   // 26 KB per block: six blocks per CU fit the 160 KB of LDS
     float* const cold_lane = &s_cold[0][threadIdx.x];
     uint32_t& item = *(uint32_t*)(cold_lane + 11 * 256);
-    f3       eye = mk3(0, 0, 0), dir = mk3(0, 0, 1);   // current index-space ray (camera walk or shadow walk)
+    typedef GeoVec<VR_GEO_IN_LDS(INTEG, EXACT, SPAN)> Geo;
+    typename Geo::type eye = Geo::make(cold_lane + 14 * 256), dir = Geo::make(cold_lane + 17 * 256);   // current index-space ray (camera walk or shadow walk)
     // voxel-span / empty-run estimates only: 1/dir (NaN where dir == 0: fminf then ignores that axis)
     // and, per axis, (dir > 0 ? 1 - slack : slack) - eye, so that the ray leaves the shrunk voxel
     // whose corner is f at t = (f + span_off) * inv
-    f3       inv = mk3(0, 0, 1), span_off = mk3(0, 0, 0);
+    typename Geo::type inv = Geo::make(cold_lane + 20 * 256), span_off = Geo::make(cold_lane + 23 * 256);
     float    t = 0, t1 = 0;             // tFar, iRay.t1()
-    float&   t0 = cold_lane[10 * 256];  // iRay.t0()
     LdsF3    wdir{cold_lane};           // data->rayDirection
     LdsF3    radiance{cold_lane + 3 * 256};   // data->radiance / result
-    // data->transmission, shadow-walk transmission.  (Tsh and t0 are never alive together, but sharing one
-    // register between them measured 2 % slower: the allocator's choices elsewhere changed.)
+    // data->transmission, shadow-walk transmission
     float    T = 1.0f, Tsh = 1.0f;
+    // iRay.t0() of the camera ray is read when its shadow walk starts, which is where Tsh is first written, and
+    // written again when the next camera ray starts, after Tsh was last read: the two share a register
+    float&   t0 = Tsh;
     float    pdf = 1.0f;                // data->rayPDF (only read with useImportanceSampling)
-    int&     depth_remaining = *(int*)(cold_lane + 14 * 256);
+    int&     depth_remaining = *(int*)(cold_lane + 10 * 256);
     LdsF3    scatter_p{cold_lane + 6 * 256};   // iRay(tFar) of the pending scatter event
     float&   scatter_len = cold_lane[9 * 256]; // its pathLength (ST_ABSORBED: mu_a of the absorbing step)
     // names the walk's stream (vr_device.h): pixel, and in one word sample (bits 0-19), bounce (20-27)
@@ -258,16 +275,20 @@ vr_track_kernel(const TrackParams p)
             if (n_off != cur_off) n_val = p.density.bricks[n_off];
             if (SPAN || SKIP)
                 // ray parameter at which the walk leaves the voxel shrunk by `slack` on every side (see empty_run)
-                n_span = fminf(fminf((fx + span_off.x) * inv.x, (fy + span_off.y) * inv.y), (fz + span_off.z) * inv.z);
+            {
+                const f3 so_ = span_off, in_ = inv;
+                n_span = fminf(fminf((fx + so_.x) * in_.x, (fy + so_.y) * in_.y), (fz + so_.z) * in_.z);
+            }
         }
         cur_val = n_val; cur_off = n_off; t_span = n_span;
     };
     // same bound for the cube of `radius` voxels around the voxel of iRay(t)
     auto cube_span = [&](float radius) -> float {
-        const f3 q = ray_at(eye, dir, t);
-        const float cx = floorf(q.x) + copysignf(radius, dir.x), cy = floorf(q.y) + copysignf(radius, dir.y),
-                    cz = floorf(q.z) + copysignf(radius, dir.z);
-        return fminf(fminf((cx + span_off.x) * inv.x, (cy + span_off.y) * inv.y), (cz + span_off.z) * inv.z);
+        const f3 d_ = dir, so_ = span_off, in_ = inv;
+        const f3 q = ray_at(eye, d_, t);
+        const float cx = floorf(q.x) + copysignf(radius, d_.x), cy = floorf(q.y) + copysignf(radius, d_.y),
+                    cz = floorf(q.z) + copysignf(radius, d_.z);
+        return fminf(fminf((cx + so_.x) * in_.x, (cy + so_.y) * in_.y), (cz + so_.z) * in_.z);
     };
     // a walk's stream: the Philox block of (pixel, sample, tag) is the generator's state
     auto seed_stream = [&]() {
