@@ -7,7 +7,6 @@ sweep() {
     timeout -k 10 120 python -u bench.py --workload $WL --spp $SPP --steps 2 --warmup 1 --cpu-baseline off 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$WL events $v', round(d['ms_per_step'],1), 'ms lanes', round(d['divergence']['walking_lanes_per_trip'],1), d['divergence']['event_phases'])" || exit 1
   done
 }
-sweep "config2_ratio_1080p_64spp_cloud512 64" 0 10 12 14 20 0
-sweep "config3_delta_1080p_256spp_cloud512 64" 0 8 10 14 16 0
-sweep "config2_textbook 64" 0 16 20 28 0
-sweep "config3_textbook 256" 0 16 20 28 0
+sweep "config2_ratio_1080p_64spp_cloud512 64" 0 12 14 20 24 0
+sweep "config3_delta_1080p_256spp_cloud512 64" 0 8 10 16 20 0
+sweep "config2_textbook 64" 0 16 20 32 0
