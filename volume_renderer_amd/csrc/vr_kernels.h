@@ -68,6 +68,7 @@ struct TrackCold {
     float     light[3], light_color[3];
     float     emission[3], medium[3], background[3];
     uint32_t  max_depth;
+    uint32_t  tile_h_log;           // work tiles are (64 >> tile_h_log) columns x (1 << tile_h_log) rows of the row set
     GridDev   temperature;
 };
 // Kernel argument: what the step loop reads.
@@ -150,6 +151,8 @@ enum {
 #endif
 #ifndef VR_TRIP_ITERS_PLAIN
 #define VR_TRIP_ITERS_PLAIN 1
+// work hand-out of the tracking kernel: vertical strips of tile columns, one per XCD
+#define VR_TRACK_STRIPS 8
 #endif
 
 // hide a pointer's provenance: loads through it stay ordinary vector loads inside the phase
@@ -256,6 +259,7 @@ vr_track_kernel(const TrackParams p)
     unsigned long long w_trips = 0, w_trip_lanes = 0, w_phases = 0;   // wave-uniform divergence counters
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's own range of work items
     bool     chunk_dry = false;               // the global counter has run past the last item
+    uint32_t strip_try = 0, strip_lo = 0, strip_w = 0;   // wave-uniform: the strip of tile columns the chunk came from
 
     // value at iRay(t) for the coming trip (nearest voxel by floor, background outside).  Results
     // are collected in locals and assigned once at the end: every state variable is then written on
@@ -416,7 +420,7 @@ vr_track_kernel(const TrackParams p)
             st = ST_NEED;
         }
         // (4) refill: idle lanes take the next items of the wave's chunk; the wave takes a new chunk
-        // from the global counter when its own is used up.  (One atomic per refill on a single
+        // from its strip's counter when its own is used up.  (One atomic per refill on a single
         // address serialises at ~11 ns each in L2 and was the bound of every short-path workload.)
         for (;;) {
             const bool               want = st == ST_NEED;
@@ -427,12 +431,29 @@ vr_track_kernel(const TrackParams p)
                     if (want) st = ST_EXHAUSTED;
                     break;
                 }
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(p.work.counter, p.work.chunk);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                chunk_next = base < p.work.nitems ? base : p.work.nitems;
-                chunk_end = base + p.work.chunk < p.work.nitems ? base + p.work.chunk : p.work.nitems;
-                if (chunk_next == chunk_end) { chunk_dry = true; continue; }
+                // one vertical strip of tile columns per XCD (workgroups go round-robin over the XCDs, each
+                // with an L2 of its own); a wave whose strip is used up helps with the next one
+                const TrackCold* c = opaque(p.cold);
+                const uint32_t tiles_x = (c->cam.width + (64u >> c->tile_h_log) - 1u) >> (6u - c->tile_h_log);
+                const uint32_t tiles_y = (c->cam.nrows + (1u << c->tile_h_log) - 1u) >> c->tile_h_log;
+                bool got = false;
+                while (strip_try < VR_TRACK_STRIPS) {
+                    const uint32_t strip = ((blockIdx.x & 7u) + strip_try) % VR_TRACK_STRIPS;
+                    strip_lo = tiles_x * strip / VR_TRACK_STRIPS;
+                    strip_w = tiles_x * (strip + 1u) / VR_TRACK_STRIPS - strip_lo;
+                    const uint32_t strip_items = strip_w * tiles_y * c->cam.s_count * 64u;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(p.work.counter + strip * 8u, p.work.chunk);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base < strip_items) {
+                        chunk_next = base;
+                        chunk_end = base + p.work.chunk < strip_items ? base + p.work.chunk : strip_items;
+                        got = true;
+                        break;
+                    }
+                    strip_try++;
+                }
+                if (!got) { chunk_dry = true; continue; }
             }
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
             const uint32_t avail = chunk_end - chunk_next, asked = (uint32_t)__popcll(need);
@@ -442,16 +463,24 @@ vr_track_kernel(const TrackParams p)
                 const uint32_t mine = first + rank;
                 {
                     const TrackCold* c = opaque(p.cold);
-                    // Work order: sub-sample by sub-sample, within one the rows from the middle of the frame
-                    // outwards (middle, +1, -1, +2, ...).  A long path takes 20-30 ms of wall time and the launch
-                    // cannot end before its last path does; the medium is usually framed, so handing the edge
-                    // rows out last leaves shorter paths for the end (measured +1 % on the headline frame, +4 %
-                    // with the camera further back; pixel-major orders were no better).
-                    const uint32_t x = mine % c->cam.width;
-                    const uint32_t q = mine / c->cam.width;
-                    const uint32_t k = q % c->cam.nrows;
-                    const uint32_t sl = q / c->cam.nrows;
-                    const uint32_t r = (k & 1u) ? c->cam.nrows / 2 - (k + 1) / 2 : c->cam.nrows / 2 + k / 2;
+                    // Work order.  Items go out as tiles of 64 pixels (8x8), all sub-samples of a tile one after the other, two tile-samples
+                    // to a chunk: their primary rays cross the same voxels, and every lookup misses L2 otherwise
+                    // (the voxel-sized-step kernels were bound by L2 misses at a 42 % hit rate; against row segments
+                    // handed out sub-sample by sub-sample: config 3 textbook +12.6 %, config 4 +21 %, config 2
+                    // textbook +6 %, configs 2 / 3 +1.6 % / +2.2 %).  Within a strip the tile rows go from the middle
+                    // of the frame outwards (middle, +1, -1, +2, ...): a long path takes 20-30 ms of wall time and
+                    // the launch cannot end before its last path does; the medium is usually framed, so handing the
+                    // edge rows out last leaves shorter paths for the end.
+                    const uint32_t th_log = c->tile_h_log, tw_log = 6u - th_log;
+                    const uint32_t tile = mine >> 6, l = mine & 63u;
+                    const uint32_t sl = tile % c->cam.s_count;
+                    const uint32_t q = tile / c->cam.s_count;
+                    const uint32_t tx = strip_lo + q % strip_w;
+                    const uint32_t k = q / strip_w;
+                    const uint32_t tiles_y = (c->cam.nrows + (1u << th_log) - 1u) >> th_log;
+                    const uint32_t ty = (k & 1u) ? tiles_y / 2 - (k + 1) / 2 : tiles_y / 2 + k / 2;
+                    const uint32_t x = (tx << tw_log) + (l & ((1u << tw_log) - 1u)), r = (ty << th_log) + (l >> tw_log);
+                    if (x >= c->cam.width || r >= c->cam.nrows) continue;   // padding of the last tile column / row
                     item = (sl * c->cam.nrows + r) * c->cam.width + x;
                     const uint32_t s = c->cam.s_first + sl;
                     const uint32_t ci = c->cam.x0 + x;
