@@ -571,8 +571,16 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
     if (npix * 3 >= (1ull << 32)) return fail(b, VR_ERR_INVALID_ARG, "row set too large");
     uint64_t per_pass = std::max<uint64_t>(1, b->sample_budget / (npix * 12));
     per_pass = std::min<uint64_t>(per_pass, spp);
-    per_pass = std::min<uint64_t>(per_pass, std::max<uint64_t>(1, 0x7fffffffull / npix));
-    if (npix * per_pass >= (1ull << 31)) return fail(b, VR_ERR_INVALID_ARG, "row set too large for one pass");
+    // The trackers hand out work tiles of 64 pixels, 8x8 over the row set, and their item space is padded to whole
+    // tiles.  (On a rank's share of 8-way interleaved rows 8x8 still beat the flatter shapes that are squarer in the
+    // image: 752 / 754 / 759 / 758 ms for 8x8 / 16x4 / 32x2 / 64x1 on rank 3's share of the N=8 headline frame.)
+    const int tile_h_log = tune_int("VR_TUNE_TILE_H_LOG", 3);
+    if (tile_h_log < 0 || tile_h_log > 6) return fail(b, VR_ERR_INVALID_ARG, "VR_TUNE_TILE_H_LOG must be in [0, 6]");
+    const uint64_t tile_w = 64u >> tile_h_log, tile_h = 1u << tile_h_log;
+    const uint64_t npix_tiled = ((o->width + tile_w - 1) / tile_w) * ((row_count + tile_h - 1) / tile_h) * 64u;
+    // item indices are 32-bit and the work counters run past the last item by a chunk per wave and strip: half the range is spare
+    per_pass = std::min<uint64_t>(per_pass, std::max<uint64_t>(1, 0x7fffffffull / npix_tiled));
+    if (npix_tiled * per_pass >= (1ull << 31)) return fail(b, VR_ERR_INVALID_ARG, "row set too large for one pass");
     rc = ensure(b, b->d_samples, b->samples_cap, (size_t)(npix * per_pass * 3));
     if (rc) return rc;
 
@@ -641,17 +649,8 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 cold.emission[i] = o->emissionColor[i]; cold.medium[i] = o->mediumColor[i]; cold.background[i] = o->backgroundColor[i];
             }
             cold.max_depth = o->maxDepth;
-            // work tiles of 64 pixels, 8x8 over the row set; the item space is padded to whole tiles.  (On a rank's
-            // share of 8-way interleaved rows 8x8 still beat the flatter shapes that are squarer in the image:
-            // 752 / 754 / 759 / 758 ms for 8x8 / 16x4 / 32x2 / 64x1 on rank 3's share of the N=8 headline frame.)
-            cold.tile_h_log = (uint32_t)tune_int("VR_TUNE_TILE_H_LOG", 3);
-            if (cold.tile_h_log > 6) return fail(b, VR_ERR_INVALID_ARG, "VR_TUNE_TILE_H_LOG must be in [0, 6]");
-            {
-                const uint64_t tw = 64u >> cold.tile_h_log, th = 1u << cold.tile_h_log;
-                const uint64_t padded = ((cam.width + tw - 1) / tw) * ((cam.nrows + th - 1) / th) * 64u * sc;
-                if (padded >= (1ull << 32)) return fail(b, VR_ERR_INVALID_ARG, "row set too large for one pass");
-                work.nitems = (uint32_t)padded;
-            }
+            cold.tile_h_log = (uint32_t)tile_h_log;
+            work.nitems = (uint32_t)(npix_tiled * sc);
             cold.temperature = b->tgrid;
             b->cold_host.push_back(cold);    // stays alive until the stream has consumed the copy
             HIP_TRY(b, hipMemcpyAsync(b->d_cold, &b->cold_host.back(), sizeof(TrackCold), hipMemcpyHostToDevice, b->stream));
