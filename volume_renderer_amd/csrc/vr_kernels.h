@@ -151,9 +151,9 @@ enum {
 #endif
 #ifndef VR_TRIP_ITERS_PLAIN
 #define VR_TRIP_ITERS_PLAIN 1
+#endif
 // work hand-out of the tracking kernel: vertical strips of tile columns, one per XCD
 #define VR_TRACK_STRIPS 8
-#endif
 
 // hide a pointer's provenance: loads through it stay ordinary vector loads inside the phase
 template <typename T>
