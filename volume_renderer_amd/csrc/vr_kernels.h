@@ -16,9 +16,9 @@
 // slots of a pixel in sample order, so the image does not depend on which lane ran which path.
 // Path lengths differ by orders of magnitude (a background pixel ends at the bbox clip, a core pixel
 // takes 10^4 steps), so the tracking kernel is persistent: a lane whose path has ended takes the next
-// item of its wave's chunk (one atomic on the global counter per chunk of 128 items) instead of idling
-// until the wave's longest path ends; items go out sub-sample by sub-sample, rows from the middle of
-// the frame outwards (see the refill).  The mesh marchers take their items in slot order, the grid
+// item of its wave's chunk (one atomic on its strip's counter per chunk of 128 items) instead of idling
+// until the wave's longest path ends; items go out as 8x8-pixel tiles, sub-samples of a tile together,
+// tile rows from the middle of the frame outwards, one strip of tile columns per XCD (see the refill).  The mesh marchers take their items in slot order, the grid
 // marchers as 8x8-pixel tiles from the same counter.
 #pragma once
 #include "vr_device.h"
@@ -258,7 +258,7 @@ vr_track_kernel(const TrackParams p)
     uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0;
     unsigned long long w_trips = 0, w_trip_lanes = 0, w_phases = 0;   // wave-uniform divergence counters
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's own range of work items
-    bool     chunk_dry = false;               // the global counter has run past the last item
+    bool     chunk_dry = false;               // every strip's counter has run past its last item
     uint32_t strip_try = 0, strip_lo = 0, strip_w = 0;   // wave-uniform: the strip of tile columns the chunk came from
 
     // value at iRay(t) for the coming trip (nearest voxel by floor, background outside).  Results
