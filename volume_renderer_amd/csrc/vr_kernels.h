@@ -177,9 +177,12 @@ struct LdsF3 {
 // The ray's geometry (origin, direction, and the two vectors of the voxel-span estimate) is read once per trip,
 // by the lookup: with it in LDS as well a FAST kernel needs 73-80 registers and six waves fit a SIMD (26 KB of
 // LDS per block, six blocks per CU).  Measured against five waves with the geometry in registers: +7 % where
-// trips are long (sub-voxel steps) and for the ratio tracker, -4 % for the delta tracker with voxel-sized
-// steps, which looks a voxel up in every iteration and keeps its geometry in registers.
-#define VR_GEO_IN_LDS(INTEG, EXACT, SPAN) (!(EXACT) && ((SPAN) || (INTEG) == INTEG_RATIO))
+// trips are long (sub-voxel steps) and for the ratio tracker; for the delta tracker with voxel-sized steps, which
+// looks a voxel up in every iteration, -4 % while that kernel was bound by L2 misses and +6-8 % once the tiled
+// work order had removed them.
+#ifndef VR_GEO_IN_LDS
+#define VR_GEO_IN_LDS(INTEG, EXACT, SPAN) (!(EXACT))
+#endif
 // Waves per SIMD the register allocator must allow (EXACT kernels: 98-123 VGPRs, four waves).
 #ifndef VR_TRACK_WAVES
 #define VR_TRACK_WAVES(INTEG, EXACT, SPAN) ((EXACT) ? 4 : (VR_GEO_IN_LDS(INTEG, EXACT, SPAN) ? 6 : 5))
