@@ -188,6 +188,34 @@ def test_render_rows_and_row_sets_tile_the_same_image(backend, oracle, cloud64):
     assert bitexact(full, out)
 
 
+@pytest.mark.parametrize("knob,value", [("VR_TUNE_TILE_H_LOG", 1), ("VR_TUNE_TILE_H_LOG", 2), ("VR_TUNE_TILE_H_LOG", 5),
+                                        ("VR_TUNE_TILE_H_LOG", 6), ("VR_TUNE_CHUNK", 64), ("VR_TUNE_ROUND_EVENTS", 3),
+                                        ("VR_TUNE_ROUND_MAX", 5)])
+def test_work_order_does_not_change_the_frame(backend, cloud64, monkeypatch, knob, value):
+    """The trackers hand their items out as tiles, strip by strip, and interleave paths within a wave by round
+    limits: every stream is keyed by pixel and sample, so tile shape, chunk size and round limits (developer knobs
+    read from the environment at each render) must leave image and counters bit-identical — on a ragged frame
+    whose width and height are not multiples of any tile shape, and whose tile columns do not fill eight strips."""
+    backend.set_density(cloud64)
+    backend.set_seed(scenes.SEED)
+    for integ, regime, mode in ((RATIO, "shipped", MODE_EXACT_SKIP), (DELTA, "textbook", MODE_FAST)):
+        o = scenes.options_cloud(integ, 64, 43, 37, 5, regime=regime)
+        backend.set_mode(mode)
+        monkeypatch.delenv(knob, raising=False)
+        base = backend.render(o, integ)
+        want = backend.last_stats()
+        monkeypatch.setenv(knob, str(value))
+        got = backend.render(o, integ)
+        st = backend.last_stats()
+        monkeypatch.delenv(knob, raising=False)
+        assert bitexact(base, got), (integ, knob, value)
+        for k in ("path_samples", "density_lookups", "scatter_events", "shadow_rays"):
+            assert st[k] == want[k], (integ, knob, value, k)
+        assert want["path_samples"] == 43 * 37 * 5
+        if knob.startswith("VR_TUNE_ROUND"):     # the knob did reach the library: the walk was cut into other rounds
+            assert st["event_phases"] != want["event_phases"]
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (3, 1, 16), (65, 2, 4), (129, 5, 1), (7, 67, 3)])
 def test_ragged_and_tiny_frames(backend, oracle, cloud64, shape):
     """Frames smaller than a wave, widths that are not multiples of 64, a single pixel, spp that is not a
