@@ -628,11 +628,13 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 integrator == VR_INTEGRATOR_NANOVDB_SIMPLE
                     ? (exact ? vr_gridmarch_kernel<false, true> : vr_gridmarch_kernel<false, false>)
                     : (exact ? vr_gridmarch_kernel<true, true> : vr_gridmarch_kernel<true, false>);
-            // persistent waves, each drawing 8x8-pixel tiles from the launch's counter
+            // grid-stride waves, each taking 8x8-pixel tiles: the item space is padded to whole tiles
             int per_cu = 8;
             rc = launch_cap(b, kern, p, per_cu);
             if (rc) return rc;
             const uint64_t ntiles = (uint64_t)((cam.width + 7) / 8) * ((cam.nrows + 7) / 8) * sc;
+            if (ntiles * 64u >= (1ull << 32)) return fail(b, VR_ERR_INVALID_ARG, "row set too large for one pass");
+            p.work.nitems = (uint32_t)(ntiles * 64u);
             const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_cu * b->num_cu, (ntiles + 3) / 4));
             HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
@@ -724,11 +726,13 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 : integrator == VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE
                     ? (exact ? vr_march_kernel<MARCH_PERLIN, true> : vr_march_kernel<MARCH_PERLIN, false>)
                     : (exact ? vr_march_kernel<MARCH_DENSITY, true> : vr_march_kernel<MARCH_DENSITY, false>);
-            // persistent waves, each drawing 8x8-pixel tiles from the launch's counter
+            // grid-stride waves, each taking 8x8-pixel tiles: the item space is padded to whole tiles
             int per_cu = 8;
             rc = launch_cap(b, kern, p, per_cu);
             if (rc) return rc;
             const uint64_t ntiles = (uint64_t)((cam.width + 7) / 8) * ((cam.nrows + 7) / 8) * sc;
+            if (ntiles * 64u >= (1ull << 32)) return fail(b, VR_ERR_INVALID_ARG, "row set too large for one pass");
+            p.work.nitems = (uint32_t)(ntiles * 64u);
             const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_cu * b->num_cu, (ntiles + 3) / 4));
             HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
