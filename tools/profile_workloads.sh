@@ -9,7 +9,7 @@ for w in config3_delta_1080p_256spp_cloud512 config3_textbook config2_textbook c
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$w -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 --cpu-baseline off > $O/$w.log 2>&1 || { tail -5 $O/$w.log; exit 1; }
   f=$(find $O/$w -name "*kernel_stats.csv" | head -1)
   cp "$f" $O/${w}_kernel_stats.csv
-  tail -1 $O/$w.log > $O/${w}_bench.json
+  grep '^{"metric"' $O/$w.log | tail -1 > $O/${w}_bench.json
   rm -rf $O/$w
   echo "== $w"; head -2 $O/${w}_kernel_stats.csv | tail -1 | cut -c1-160
 done
