@@ -75,7 +75,7 @@ int vr_backend_set_mesh(vr_backend* b, const vr_mesh_desc* mesh);
 int vr_backend_set_mode(vr_backend* b, int vr_mode);          /* default VR_MODE_FAST */
 int vr_backend_set_seed(vr_backend* b, uint64_t philox_key);  /* default 0x5EED0001   */
 /* Cap on the per-sample staging buffer in HBM (bytes); samples are rendered in passes that
- * fit.  Default 4 GiB. */
+ * fit (the buffer grows to what a frame needs, never beyond the cap).  Default 32 GiB. */
 int vr_backend_set_sample_buffer_bytes(vr_backend* b, uint64_t bytes);
 
 /* ---- the hot path -----------------------------------------------------------------------

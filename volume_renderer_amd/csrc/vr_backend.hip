@@ -213,7 +213,7 @@ struct vr_backend {
     int           num_cu = 256;
     int           mode = VR_MODE_FAST;
     uint64_t      seed = 0x5EED0001ull;
-    uint64_t      sample_budget = 4ull << 30;
+    uint64_t      sample_budget = 32ull << 30;   // of 288 GB: config 4 (4K at 256 spp, 25.5 GB of samples) in one launch
 
     // density / temperature
     bool     has_density = false, has_temperature = false;
