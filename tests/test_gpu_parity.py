@@ -273,6 +273,37 @@ def test_tracking_fast_mode_tracks_the_oracle(backend, oracle, cloud64, integ):
     assert abs(st["density_lookups"] - wst["density_lookups"]) / wst["density_lookups"] < 5e-3
 
 
+def test_marcher_tiles_and_row_sets_give_the_same_frame(backend, monkeypatch):
+    """The mesh marchers take 8x8-pixel tiles over consecutive rows and 16x4 over interleaved row sets; neither the
+    tile shape nor the row partition may change a pixel or a count (ragged frame: 45 x 39)."""
+    import torch
+    backend.set_mesh(scenes.icosphere_mesh())
+    backend.set_mode(MODE_EXACT)
+    backend.set_seed(scenes.SEED)
+    W, H = 45, 39
+    o = scenes.options_marcher(W, H, 3)
+    for integ in (NEE, IMPROVED):
+        monkeypatch.delenv("VR_TUNE_MARCH_TILE_H_LOG", raising=False)
+        full = backend.render(o, integ)
+        want = backend.last_stats()
+        assert want["path_samples"] == W * H * 3
+        for h_log in (1, 2, 5, 6):
+            monkeypatch.setenv("VR_TUNE_MARCH_TILE_H_LOG", str(h_log))
+            assert bitexact(full, backend.render(o, integ)), (integ, h_log)
+            st = backend.last_stats()
+            assert st["ray_queries"] == want["ray_queries"] and st["path_samples"] == want["path_samples"]
+        monkeypatch.delenv("VR_TUNE_MARCH_TILE_H_LOG", raising=False)
+        for stride in (2, 5):                                   # 8x8 tiles below a stride of 4, 16x4 from there on
+            out = np.zeros_like(full)
+            for r in range(stride):
+                rows = len(range(r, H, stride))
+                dev = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda:0")
+                backend.render_row_set_device(o, integ, r, stride, rows, dev.data_ptr())
+                backend.synchronize()
+                out[r::stride] = dev.cpu().numpy()
+            assert bitexact(full, out), (integ, stride)
+
+
 @pytest.mark.parametrize("mesh_name", ["cube", "icosphere", "two_objects"])
 @pytest.mark.parametrize("integ", [NEE, IMPROVED, PERLIN])
 def test_marchers_exact_mode_is_bit_identical(backend, oracle, mesh_name, integ):

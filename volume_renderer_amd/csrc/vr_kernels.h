@@ -727,6 +727,7 @@ struct MarchParams {
     float     sigma_a, sigma_s, g;
     float     light[3], light_color[3], background[3];
     uint32_t  max_depth;
+    uint32_t  tile_h_log;
 };
 
 // Moeller-Trumbore with the operation order of the oracle's tri_hit (stand-in for rtcIntersect1,
@@ -799,14 +800,17 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
     uint32_t n_queries = 0, n_light = 0, n_paths = 0;
     // a wave takes an 8x8-pixel tile (p.work.nitems counts whole tiles): its 64 rays visit nearly the same BVH nodes
     // and triangles, which a wave executes as the union over its lanes (+10-17 % against 64 pixels of a row)
-    const uint32_t tiles_x = (p.cam.width + 7u) >> 3, tiles_y = (p.cam.nrows + 7u) >> 3;
+    // (the tile is (64 >> tile_h_log) x (1 << tile_h_log) pixels of the row set: flatter when the rows are a rank's
+    // share of an interleaved frame, so that it stays compact in the image)
+    const uint32_t th_log = p.tile_h_log, tw_log = 6u - th_log;
+    const uint32_t tiles_x = (p.cam.width + (1u << tw_log) - 1u) >> tw_log, tiles_y = (p.cam.nrows + (1u << th_log) - 1u) >> th_log;
     for (uint32_t mine = blockIdx.x * blockDim.x + threadIdx.x; mine < p.work.nitems; mine += gridDim.x * blockDim.x) {
         const uint32_t tile = mine >> 6, l = mine & 63u;
         const uint32_t tx = tile % tiles_x;
         const uint32_t q = tile / tiles_x;
         const uint32_t ty = q % tiles_y;
         const uint32_t sl = q / tiles_y;
-        const uint32_t x = tx * 8u + (l & 7u), r = ty * 8u + (l >> 3);
+        const uint32_t x = (tx << tw_log) + (l & ((1u << tw_log) - 1u)), r = (ty << th_log) + (l >> tw_log);
         if (x >= p.cam.width || r >= p.cam.nrows) continue;   // padding of the last tile column / row (no wave-level operation below)
         const uint32_t item = (sl * p.cam.nrows + r) * p.cam.width + x;
         const uint32_t s = p.cam.s_first + sl;
