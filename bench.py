@@ -32,7 +32,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: the backend shares torch's HIP runtime)
@@ -79,9 +78,10 @@ def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None):
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
 
+    sys.path.insert(0, os.path.join(ROOT, "tests"))      # the oracle's loader: this leg only
     import oracle_lib as ol
     from volume_renderer_amd.abi import Grid, copy_options
-    import scenes
+    from volume_renderer_amd import workloads as scenes
 
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 64)
     L = ol.lib()
@@ -146,7 +146,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from volume_renderer_amd import MODE_EXACT, MODE_FAST, Backend, INTEGRATORS
-    import scenes
+    from volume_renderer_amd import workloads as scenes
 
     integ, n, W, H, spp, regime = WORKLOADS[a.workload]
     if a.spp:

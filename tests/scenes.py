@@ -1,105 +1,4 @@
-"""Synthetic scenes and option sets for the parity tests and bench.py.
-
-The reference's real fields (bunny_cloud.nvdb, fire.nvdb) are absent from its checkout, so
-every heterogeneous case uses the procedural cloud; meshes are generated here rather than
-read from the reference's Models/ (which does not exist on the GPU box).
-"""
-import numpy as np
-
-from volume_renderer_amd.abi import Mesh, copy_options, default_options
-
-SEED = 0x5EED0001
-
-BACKGROUND_SKY = (0.36 * 4.0, 0.702 * 4.0, 0.98 * 4.0)  # bunny-cloud-configRenderer.xml:43
-
-
-def cube_mesh(side=4.0, center=(0.0, 0.5, 0.0), dissolve=0.5):
-    """Axis-aligned cube, 12 triangles, one medium material (`d 0.5`) — BASELINE config 1."""
-    h = side / 2.0
-    c = np.array(center, dtype=np.float32)
-    v = np.array([[x, y, z] for x in (-h, h) for y in (-h, h) for z in (-h, h)], dtype=np.float32) + c
-    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
-    tris = []
-    for a, b, c_, d in quads:
-        tris += [(a, b, c_), (a, c_, d)]
-    return Mesh(v, np.array(tris, dtype=np.uint32), np.zeros(len(tris), dtype=np.uint32),
-                np.array([dissolve], dtype=np.float32))
-
-
-def icosphere_mesh(radius=2.55, center=(0.0, 0.5, 0.0), subdivisions=2, dissolve=0.5):
-    """Icosphere with 20*4^subdivisions triangles (320 at level 2, the size of the reference's
-    SphereOnly.obj asset)."""
-    t = (1.0 + 5.0 ** 0.5) / 2.0
-    verts = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
-             (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
-    verts = [np.array(v, dtype=np.float64) / np.linalg.norm(v) for v in verts]
-    faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
-             (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
-             (8, 6, 7), (9, 8, 1)]
-    for _ in range(subdivisions):
-        cache = {}
-
-        def mid(a, b):
-            key = (min(a, b), max(a, b))
-            if key not in cache:
-                m = verts[a] + verts[b]
-                verts.append(m / np.linalg.norm(m))
-                cache[key] = len(verts) - 1
-            return cache[key]
-
-        nf = []
-        for a, b, c in faces:
-            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
-            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
-        faces = nf
-    v = (np.array(verts) * radius + np.array(center)).astype(np.float32)
-    return Mesh(v, np.array(faces, dtype=np.uint32), np.zeros(len(faces), dtype=np.uint32),
-                np.array([dissolve], dtype=np.float32))
-
-
-def two_object_mesh():
-    """A medium cube in front of a medium sphere: exercises the previousObjectId != objectId walk."""
-    a = cube_mesh(side=2.0, center=(-0.6, 0.5, 1.5))
-    b = icosphere_mesh(radius=1.6, center=(0.8, 0.6, -1.0), subdivisions=1)
-    v = np.concatenate([a.verts, b.verts])
-    t = np.concatenate([a.tris, b.tris + len(a.verts)])
-    p2s = np.concatenate([np.zeros(len(a.tris)), np.ones(len(b.tris))]).astype(np.uint32)
-    return Mesh(v, t, p2s, np.array([0.5, 1.0], dtype=np.float32))
-
-
-def options_marcher(width=512, height=512, spp=1, **kw):
-    """BASELINE config 1: homogeneousRayMarcherNEE plumbing case (configRenderer.xml:43,56 camera/light)."""
-    o = default_options(width=width, height=height, widthReference=width, heightReference=height,
-                        rayPerPixelCount=spp, maxDepth=16, sigma_a=0.5, sigma_s=0.5, heyneyGreensteinG=0.4,
-                        cameraPosition=(0.0, 0.825, 6.75), fov=60.0, lightPosition=(0.0, 1.0, 0.0),
-                        lightColor=(1.965, 0.45, 1.35), backgroundColor=(0.572, 0.772, 0.921))
-    return copy_options(o, **kw)
-
-
-def options_cloud(integrator, n, width, height, spp, regime="shipped", **kw):
-    """BASELINE configs 2/3 on an n^3 cloud of radius 240/512*n voxels, camera on +z at 2.2 R, fov 45.
-
-    regime "shipped": the step parameters of bunny-cloud-configRenderer.xml:9-14 (ratio) /
-    bunny-cloud-deltaTracking-configRenderer.xml:9-14 (delta); "textbook": multiplier 1,
-    min 1e-4 scaled to the grid, max 1e30.
-    """
-    R = cloud_radius(n)
-    base = dict(width=width, height=height, widthReference=width, heightReference=height, rayPerPixelCount=spp,
-                maxDepth=16, cameraPosition=(0.0, 0.0, 2.2 * R), fov=45.0, lightPosition=(0.0, 1.0, 0.0),
-                lightColor=(1024.0, 1024.0, 1024.0), backgroundColor=BACKGROUND_SKY)
-    if integrator in ("ratioTracking", 2):
-        base.update(sigma_a=0.01, sigma_s=0.09, heyneyGreensteinG=0.924, stepSizeMin=0.005, stepSizeMax=9999.9,
-                    stepSizeMultiplier=0.001)
-    else:
-        base.update(sigma_a=0.1, sigma_s=0.9, heyneyGreensteinG=-0.2, stepSizeMin=0.01, stepSizeMax=9999.9,
-                    stepSizeMultiplier=0.0001)
-    if regime == "textbook":
-        base.update(stepSizeMin=1e-3, stepSizeMax=1e30, stepSizeMultiplier=1.0)
-    elif regime != "shipped":
-        raise ValueError(regime)
-    base.update(kw)
-    return default_options(**base)
-
-
-def cloud_radius(n):
-    return 240.0 / 512.0 * n
+"""Scenes of the parity tests: the workload definitions live in the package (volume_renderer_amd/workloads.py),
+so that bench.py does not import from tests/."""
+from volume_renderer_amd.workloads import *  # noqa: F401,F403
+from volume_renderer_amd.workloads import SEED, BACKGROUND_SKY  # noqa: F401

@@ -49,23 +49,56 @@ def write_png(path, rgb8):
 
 
 def read_png_rgb8(path):
-    """Inverse of write_png for the files it writes (8-bit RGB, filter 0 only); used by the tests."""
+    """8-bit, non-interlaced RGB or RGBA PNG -> (h, w, 3) uint8, row 0 on top.  Reads what write_png writes and
+    what the reference's FreeImage_Save wrote (its committed renders; adaptive row filters 0-4); used by the tests."""
     with open(path, "rb") as f:
         data = f.read()
     assert data[:8] == b"\x89PNG\r\n\x1a\n"
-    pos, idat, w, h = 8, b"", 0, 0
+    pos, idat, w, h, bpp = 8, b"", 0, 0, 3
     while pos < len(data):
         n, tag = struct.unpack(">I4s", data[pos:pos + 8])
         body = data[pos + 8:pos + 8 + n]
         if tag == b"IHDR":
-            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
-            assert (depth, ctype) == (8, 2)
+            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body[:13])
+            assert depth == 8 and ctype in (2, 6) and interlace == 0, "8-bit non-interlaced RGB(A) only"
+            bpp = 3 if ctype == 2 else 4
         elif tag == b"IDAT":
             idat += body
         pos += 12 + n
-    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + 3 * w)
-    assert not raw[:, 0].any()
-    return raw[:, 1:].reshape(h, w, 3).copy()
+    stride = bpp * w
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + stride)
+    out = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        ft = int(raw[y, 0])
+        line = raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:                                        # Up
+            cur = (line + prev) & 255
+        elif ft == 1:                                        # Sub: a prefix sum per channel
+            cur = (np.cumsum(line.reshape(w, bpp), axis=0) & 255).reshape(stride)
+        else:                                                # Average / Paeth: sequential in x
+            cur = np.zeros(stride, dtype=np.int32)
+            ln, pv = line.tolist(), prev.tolist()
+            acc = [0] * stride
+            for i in range(stride):
+                a = acc[i - bpp] if i >= bpp else 0
+                b = pv[i]
+                if ft == 3:
+                    pred = (a + b) >> 1
+                elif ft == 4:
+                    c = pv[i - bpp] if i >= bpp else 0
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                else:
+                    raise ValueError(f"PNG filter type {ft}")
+                acc[i] = (ln[i] + pred) & 255
+            cur = np.array(acc, dtype=np.int32)
+        out[y] = cur
+        prev = cur
+    return out.reshape(h, w, bpp)[:, :, :3].copy()
 
 
 def find_dense_grids(cfg, density=None, temperature=None):
