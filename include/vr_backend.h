@@ -97,8 +97,12 @@ int vr_backend_render(vr_backend* b, const vr_options_pod* o, int integrator, fl
  * reference's chunk queue, BaseIntegrator.cpp:253-285 + Utils/MultithreadingHelper.cpp:10-28,
  * hands out row chunks; here rank r of N takes rows row_first + k*row_stride):
  * renders rows heightStartOffset + row_first + k*row_stride, k = 0..row_count-1, into
- * d_rgb = DEVICE pointer to row_count*width*3 floats.  Asynchronous on the backend's stream;
- * vr_backend_synchronize waits for it. */
+ * d_rgb = DEVICE pointer to row_count*width*3 floats.  Asynchronous on the backend's stream
+ * (nothing is copied from host memory and the call does not wait for earlier work on the stream,
+ * so consecutive frames or row sets queue up behind each other); vr_backend_synchronize waits for it.
+ * The backend's stream is its own, non-blocking one: work that other streams (torch's, the
+ * caller's) have queued on d_rgb must be complete before this call, and the caller must
+ * vr_backend_synchronize before another stream reads d_rgb. */
 int vr_backend_render_row_set_device(vr_backend* b, const vr_options_pod* o, int integrator,
                                      uint32_t row_first, uint32_t row_stride, uint32_t row_count,
                                      void* d_rgb);
@@ -113,7 +117,9 @@ int vr_backend_last_stats(vr_backend* b, vr_render_stats* stats, float* kernel_m
  * (BaseIntegrator.cpp:199-220) on a DEVICE buffer of npixels RGB triples, in place.
  * max_white_in < 0: compute the maximum from the buffer (single GPU); otherwise use the
  * given global maximum (multi-GPU: all-reduce MAX the per-rank maxima first).
- * max_white_out may be NULL. */
+ * max_white_out may be NULL.  Both run on the backend's own stream and wait for it before they
+ * return: a d_rgb that another stream produced (an RCCL gather on torch's stream) must be complete
+ * before the call. */
 int vr_backend_tonemap_device(vr_backend* b, void* d_rgb, uint64_t npixels, float max_white_in, float* max_white_out);
 int vr_backend_max_channel_device(vr_backend* b, const void* d_rgb, uint64_t npixels, float* max_out);
 /* Replaces the pixel loop of BaseIntegrator::saveFile (BaseIntegrator.cpp:19-25): clamp to

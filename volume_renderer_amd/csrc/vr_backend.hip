@@ -177,29 +177,41 @@ __global__ void __launch_bounds__(256) k_tonemap(float* __restrict__ rgb, size_t
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// host restatements of the per-frame constants
-// ---------------------------------------------------------------------------------------------
-
-// BaseIntegrator::assignPointToQuadrant (BaseIntegrator.cpp:112-129)
-void quadrant_offset(int i, int total, float& ox, float& oy)
+// BaseIntegrator::assignPointToQuadrant (BaseIntegrator.cpp:112-129) for every sub-sample of a frame, on the
+// device: the recursion unrolled into a descent (which quadrant at each level) and the sums taken from the
+// innermost level outwards, as the recursion returns them.  spp <= 2^20: at most nine levels above the base case.
+__global__ void __launch_bounds__(256) k_quadrant_offsets(float2* __restrict__ out, uint32_t spp)
 {
-    ox = 0.0f; oy = 0.0f;
-    if (total < 4) return;
-    if (total == 4) {
-        ox = (i == 0 || i == 1) ? 0.25f : -0.25f;
-        oy = (i == 0 || i == 2) ? 0.25f : -0.25f;
-        return;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < spp; s += gridDim.x * blockDim.x) {
+        int idx[12], tot[12], n = 0;
+        int i = (int)s, total = (int)spp;
+        while (total > 4 && n < 12) {                               // :123 recurse with (i % (total/4), total/4)
+            idx[n] = i; tot[n] = total; n++;
+            i = i % (total / 4); total = total / 4;
+        }
+        float ox = 0.0f, oy = 0.0f;                                 // :113 total < 4
+        if (total == 4) {                                           // :115-120
+            ox = (i == 0 || i == 1) ? 0.25f : -0.25f;
+            oy = (i == 0 || i == 2) ? 0.25f : -0.25f;
+        }
+        while (n-- > 0) {
+            i = idx[n]; total = tot[n];
+            const float value = 1.0f / total;                       // :122
+            float sx, sy;
+            if (i < total / 4.0f)          { sx = value;  sy = value; }
+            else if (i < 2 * total / 4.0f) { sx = value;  sy = -value; }
+            else if (i < 3 * total / 4.0f) { sx = -value; sy = value; }
+            else                           { sx = -value; sy = -value; }
+            ox = sx + ox; oy = sy + oy;                             // :128 offset + recursive result
+        }
+        out[s] = make_float2(ox, oy);
     }
-    float rx, ry;
-    quadrant_offset(i % (total / 4), total / 4, rx, ry);
-    const float value = 1.0f / total;
-    float sx, sy;
-    if (i < total / 4.0f)          { sx = value;  sy = value; }
-    else if (i < 2 * total / 4.0f) { sx = value;  sy = -value; }
-    else if (i < 3 * total / 4.0f) { sx = -value; sy = value; }
-    else                           { sx = -value; sy = -value; }
-    ox = sx + rx; oy = sy + ry;
+}
+
+// the event phases' parameter block goes to HBM as a kernel argument: no host buffer has to outlive the call
+__global__ void k_store_cold(const TrackCold c, TrackCold* __restrict__ dst)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = c;
 }
 
 struct Pass { hipEvent_t e0, e1; };
@@ -236,11 +248,16 @@ struct vr_backend {
     Counters* d_counters = nullptr;
     int*      d_maxbits = nullptr;
 
-    TrackCold*             d_cold = nullptr;
-    std::vector<TrackCold> cold_host;
+    TrackCold*        d_cold = nullptr;
     std::vector<Pass> passes;
     size_t            passes_used = 0;
+    uint32_t          launches = 0;           // integrator kernel launches of the last render call
     vr_render_stats   stats{};
+    // developer knobs (VR_TUNE_*), read at the start of each render call; 0 = built-in default
+    int tune_tile_h_log = 0, tune_round_max = 0, tune_round_events = 0, tune_chunk = 0, tune_march_tile_h_log = 0, tune_bvh_leaf = 0;
+    // hipOccupancyMaxActiveBlocksPerMultiprocessor per kernel, asked once
+    struct { const void* kernel; int blocks; } occupancy[64]{};
+    int noccupancy = 0;
 };
 
 namespace {
@@ -273,9 +290,10 @@ template <typename T>
 int ensure(vr_backend* b, T*& ptr, size_t& cap, size_t count)
 {
     if (count <= cap && ptr) return VR_OK;
-    if (ptr) { HIP_TRY(b, hipFree(ptr)); ptr = nullptr; cap = 0; }
-    HIP_TRY(b, hipMalloc((void**)&ptr, count * sizeof(T)));
-    cap = count;
+    T* fresh = nullptr;     // the old buffer stays until the larger one exists: a failed grow leaves it usable
+    HIP_TRY(b, hipMalloc((void**)&fresh, count * sizeof(T)));
+    if (ptr) (void)hipFree(ptr);
+    ptr = fresh; cap = count;
     return VR_OK;
 }
 
@@ -366,8 +384,6 @@ void set_map(vr_backend* b, const float* inv_mat, const float* vec, const float*
     for (int i = 0; i < 3; ++i) { b->bmin[i] = (float)bmin[i]; b->bmax1[i] = (float)(bmax[i] + 1); }   // Ray.h:401
 }
 
-int tune_int(const char* name, int dflt);
-
 // ---- threaded BVH (replaces the Embree scene, SceneLoader.cpp:150-199) ----
 struct BuildTri { float lo[3], hi[3], c[3]; uint32_t prim; };
 
@@ -377,7 +393,8 @@ struct BuildTri { float lo[3], hi[3], c[3]; uint32_t prim; };
 // against the hit already found.
 struct TreeNode { BvhNode box; int axis; uint32_t left, right; };
 
-uint32_t build_bvh(std::vector<BuildTri>& t, uint32_t first, uint32_t count, std::vector<TreeNode>& tree, std::vector<uint32_t>& order)
+uint32_t build_bvh(std::vector<BuildTri>& t, uint32_t first, uint32_t count, std::vector<TreeNode>& tree, std::vector<uint32_t>& order,
+                   uint32_t leaf_size)
 {
     TreeNode tn{};
     BvhNode& nd = tn.box;
@@ -399,7 +416,7 @@ uint32_t build_bvh(std::vector<BuildTri>& t, uint32_t first, uint32_t count, std
     tree.push_back(tn);
     int axis = 0;
     for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-    if (count <= (uint32_t)tune_int("VR_TUNE_BVH_LEAF", 1) || !(chi[axis] > clo[axis])) {
+    if (count <= leaf_size || !(chi[axis] > clo[axis])) {
         tree[me].box.first = (uint32_t)order.size();
         tree[me].box.count = count;
         for (uint32_t i = first; i < first + count; ++i) order.push_back(i);
@@ -409,8 +426,8 @@ uint32_t build_bvh(std::vector<BuildTri>& t, uint32_t first, uint32_t count, std
                          [axis](const BuildTri& x, const BuildTri& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.prim < y.prim); });
         tree[me].box.first = 0; tree[me].box.count = 0;
         tree[me].axis = axis;
-        const uint32_t l = build_bvh(t, first, mid, tree, order);             // lower centroids along `axis`
-        const uint32_t r = build_bvh(t, first + mid, count - mid, tree, order);
+        const uint32_t l = build_bvh(t, first, mid, tree, order, leaf_size);             // lower centroids along `axis`
+        const uint32_t r = build_bvh(t, first + mid, count - mid, tree, order, leaf_size);
         tree[me].left = l; tree[me].right = r;
     }
     return me;
@@ -435,7 +452,7 @@ struct Frame {
 };
 
 // renderPartial's constants (BaseIntegrator.cpp:288-312) and Utils::rotate's matrix (Utils.cpp:30-53)
-int make_camera(vr_backend* b, const vr_options_pod* o, CameraDev& c)
+void make_camera(const vr_options_pod* o, CameraDev& c)
 {
     memset(&c, 0, sizeof c);
     const float width = o->widthReference > 0.0f ? (float)o->widthReference : (float)o->width;
@@ -466,25 +483,26 @@ int make_camera(vr_backend* b, const vr_options_pod* o, CameraDev& c)
         c.rot[3] = sina * cosb; c.rot[4] = sina * sinb * sinc + cosa * cosc; c.rot[5] = sina * sinb * cosc - cosa * sinc;
         c.rot[6] = -sinb;       c.rot[7] = cosb * sinc;                      c.rot[8] = cosb * cosc;
     }
-    // quadrant offsets per sub-sample
-    const uint32_t spp = o->rayPerPixelCount;
-    if (ensure(b, b->d_offsets, b->offsets_cap, (size_t)spp)) return VR_ERR_HIP;
-    std::vector<float2> off(spp);
-    for (uint32_t s = 0; s < spp; ++s) quadrant_offset((int)s, (int)spp, off[s].x, off[s].y);
-    HIP_TRY(b, hipMemcpyAsync(b->d_offsets, off.data(), spp * sizeof(float2), hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(b, hipStreamSynchronize(b->stream));   // `off` goes out of scope
-    c.offsets = b->d_offsets;
-    c.spp = spp;
-    return VR_OK;
+    c.spp = o->rayPerPixelCount;   // c.offsets: k_quadrant_offsets fills them on the device (render_row_set)
 }
 
-// developer knob: integer from the environment, else the built-in default
-int tune_int(const char* name, int dflt)
+// developer knob: positive integer from the environment, else 0 (= the built-in default)
+int tune_env(const char* name)
 {
     const char* v = getenv(name);
-    if (!v || !*v) return dflt;
+    if (!v || !*v) return 0;
     const int x = atoi(v);
-    return x > 0 ? x : dflt;
+    return x > 0 ? x : 0;
+}
+inline int tuned(int knob, int dflt) { return knob > 0 ? knob : dflt; }
+// the VR_TUNE_* knobs, read once per render call / mesh upload (not per pass or per BVH node)
+void read_knobs(vr_backend* b)
+{
+    auto plus1 = [](const char* name) { const char* v = getenv(name); return v && *v ? atoi(v) + 1 : 0; };   // 0 is a valid value
+    b->tune_tile_h_log = plus1("VR_TUNE_TILE_H_LOG");
+    b->tune_march_tile_h_log = plus1("VR_TUNE_MARCH_TILE_H_LOG");
+    b->tune_round_max = tune_env("VR_TUNE_ROUND_MAX"); b->tune_round_events = tune_env("VR_TUNE_ROUND_EVENTS");
+    b->tune_chunk = tune_env("VR_TUNE_CHUNK"); b->tune_bvh_leaf = tune_env("VR_TUNE_BVH_LEAF");
 }
 
 float ulp_of(float v)
@@ -543,7 +561,12 @@ template <typename K, typename P>
 int launch_cap(vr_backend* b, K kernel, const P&, int& blocks_per_cu)
 {
     int nb = 0;
-    HIP_TRY(b, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0));
+    for (int i = 0; i < b->noccupancy; ++i)
+        if (b->occupancy[i].kernel == (const void*)kernel) nb = b->occupancy[i].blocks;
+    if (nb == 0) {
+        HIP_TRY(b, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0));
+        if (b->noccupancy < 64) { b->occupancy[b->noccupancy].kernel = (const void*)kernel; b->occupancy[b->noccupancy].blocks = nb; b->noccupancy++; }
+    }
     blocks_per_cu = std::max(1, std::min(nb, 8));
     return VR_OK;
 }
@@ -561,57 +584,80 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
         return fail(b, VR_ERR_INVALID_ARG, "row set exceeds height %u", o->height);
     if (!d_out) return fail(b, VR_ERR_INVALID_ARG, "output == NULL");
 
+    read_knobs(b);
     CameraDev cam;
-    rc = make_camera(b, o, cam);
-    if (rc) return rc;
+    make_camera(o, cam);
     cam.row_first = row_first; cam.row_stride = row_stride; cam.nrows = row_count;
 
     const uint32_t spp = o->rayPerPixelCount;
     const uint64_t npix = (uint64_t)row_count * o->width;
     if (npix * 3 >= (1ull << 32)) return fail(b, VR_ERR_INVALID_ARG, "row set too large");
-    uint64_t per_pass = std::max<uint64_t>(1, b->sample_budget / (npix * 12));
+    const uint64_t budget = b->sample_budget;
+    uint64_t per_pass = std::max<uint64_t>(1, budget / (npix * 12));
     per_pass = std::min<uint64_t>(per_pass, spp);
     // The trackers hand out work tiles of 64 pixels, 8x8 over the row set, and their item space is padded to whole
     // tiles.  (On a rank's share of 8-way interleaved rows 8x8 still beat the flatter shapes that are squarer in the
     // image: 752 / 754 / 759 / 758 ms for 8x8 / 16x4 / 32x2 / 64x1 on rank 3's share of the N=8 headline frame.)
-    const int tile_h_log = tune_int("VR_TUNE_TILE_H_LOG", 3);
+    const int tile_h_log = b->tune_tile_h_log > 0 ? b->tune_tile_h_log - 1 : 3;      // (the knob is stored + 1: 0 is a valid value)
     if (tile_h_log < 0 || tile_h_log > 6) return fail(b, VR_ERR_INVALID_ARG, "VR_TUNE_TILE_H_LOG must be in [0, 6]");
     const uint64_t tile_w = 64u >> tile_h_log, tile_h = 1u << tile_h_log;
     const uint64_t npix_tiled = ((o->width + tile_w - 1) / tile_w) * ((row_count + tile_h - 1) / tile_h) * 64u;
     // item indices are 32-bit and the work counters run past the last item by a chunk per wave and strip: half the range is spare
     per_pass = std::min<uint64_t>(per_pass, std::max<uint64_t>(1, 0x7fffffffull / npix_tiled));
     if (npix_tiled * per_pass >= (1ull << 31)) return fail(b, VR_ERR_INVALID_ARG, "row set too large for one pass");
-    rc = ensure(b, b->d_samples, b->samples_cap, (size_t)(npix * per_pass * 3));
+
+    // the staging buffer grows to what the frame needs; when HBM does not have it (other users of the GPU, a
+    // smaller device) render in more passes rather than fail
+    for (;;) {
+        rc = ensure(b, b->d_samples, b->samples_cap, (size_t)(npix * per_pass * 3));
+        if (rc != VR_ERR_OUT_OF_MEMORY || per_pass == 1) break;
+        (void)hipGetLastError();
+        per_pass = (per_pass + 1) / 2;
+    }
     if (rc) return rc;
+    rc = ensure(b, b->d_offsets, b->offsets_cap, (size_t)spp);
+    if (rc) return rc;
+    uint32_t* const  d_work = b->d_work;
+    Counters* const  d_counters = b->d_counters;
+    TrackCold* const d_cold = b->d_cold;
+    float2* const    d_offsets = b->d_offsets;
+    float* const     d_samples = b->d_samples;
+    cam.offsets = d_offsets;
+    k_quadrant_offsets<<<(spp + 255) / 256 > 256 ? 256 : (spp + 255) / 256, 256, 0, b->stream>>>(d_offsets, spp);
+    HIP_TRY(b, hipGetLastError());
 
     // the voxel-span / empty-run estimates assume ray parameters of at most a few thousand voxels
     bool span_ok = true;
     const bool tracking = integrator == VR_INTEGRATOR_RATIO_TRACKING || integrator == VR_INTEGRATOR_DELTA_TRACKING;
     if (tracking) span_ok = tracking_t_max(b, o) < 8000.0f;
-    b->cold_host.clear();
-    b->cold_host.reserve(spp + 1);
 
     WorkDev work{};
-    work.counter = b->d_work; work.samples = b->d_samples; work.counters = b->d_counters;
+    work.counter = d_work; work.samples = d_samples; work.counters = d_counters;
     work.key0 = (uint32_t)b->seed; work.key1 = (uint32_t)(b->seed >> 32);
     work.step_limit = 1u << 28;
 
-    HIP_TRY(b, hipMemsetAsync(b->d_counters, 0, sizeof(Counters), b->stream));
+    HIP_TRY(b, hipMemsetAsync(d_counters, 0, sizeof(Counters), b->stream));
     b->passes_used = 0;
+    b->launches = 0;
     const bool exact = b->mode != VR_MODE_FAST;
+    const bool timed = true;
 
     for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)per_pass) {
         const uint32_t sc = (uint32_t)std::min<uint64_t>(per_pass, spp - s0);
         cam.s_first = s0; cam.s_count = sc;
         work.nitems = (uint32_t)(npix * sc);
-        if (b->passes_used == b->passes.size()) {
-            Pass p{};
-            HIP_TRY(b, hipEventCreate(&p.e0));
-            HIP_TRY(b, hipEventCreate(&p.e1));
-            b->passes.push_back(p);
+        Pass ev{};
+        if (timed) {
+            if (b->passes_used == b->passes.size()) {
+                Pass p{};
+                HIP_TRY(b, hipEventCreate(&p.e0));
+                HIP_TRY(b, hipEventCreate(&p.e1));
+                b->passes.push_back(p);
+            }
+            ev = b->passes[b->passes_used++];
         }
-        Pass& ev = b->passes[b->passes_used++];
-        HIP_TRY(b, hipMemsetAsync(b->d_work, 0, 256, b->stream));   // the item counter (grid marchers: one per strip, 32 B apart)
+        b->launches++;
+        HIP_TRY(b, hipMemsetAsync(d_work, 0, 256, b->stream));   // the item counter (grid marchers: one per strip, 32 B apart)
 
         if (integrator == VR_INTEGRATOR_NANOVDB_SIMPLE || integrator == VR_INTEGRATOR_NANOVDB_EMISSION) {
             GridMarchParams p{};
@@ -634,10 +680,10 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             if (rc) return rc;
             const uint64_t ntiles = (uint64_t)((cam.width + 7) / 8) * ((cam.nrows + 7) / 8) * sc;
             const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_cu * b->num_cu, (ntiles + 3) / 4));
-            HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
+            if (timed) HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
             HIP_TRY(b, hipGetLastError());
-            HIP_TRY(b, hipEventRecord(ev.e1, b->stream));
+            if (timed) HIP_TRY(b, hipEventRecord(ev.e1, b->stream));
         } else if (tracking) {
             TrackCold cold{};
             cold.cam = cam;
@@ -652,10 +698,10 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             cold.tile_h_log = (uint32_t)tile_h_log;
             work.nitems = (uint32_t)(npix_tiled * sc);
             cold.temperature = b->tgrid;
-            b->cold_host.push_back(cold);    // stays alive until the stream has consumed the copy
-            HIP_TRY(b, hipMemcpyAsync(b->d_cold, &b->cold_host.back(), sizeof(TrackCold), hipMemcpyHostToDevice, b->stream));
+            k_store_cold<<<1, 64, 0, b->stream>>>(cold, d_cold);
+            HIP_TRY(b, hipGetLastError());
             TrackParams p{};
-            p.cold = b->d_cold; p.work = work;
+            p.cold = d_cold; p.work = work;
             p.density = b->grid;
             const bool temp = b->has_temperature;
             const bool is = o->useImportanceSampling != 0;
@@ -674,8 +720,8 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             // a round of the step loop ends after round_max trips or when round_events lanes wait for the
             // event phase (measured per regime: sub-voxel steps have long trips and rare events, voxel-sized
             // steps one iteration per trip and an event every few iterations)
-            p.round_max = tune_int("VR_TUNE_ROUND_MAX", span ? VR_ROUND_MAX : 2 * VR_ROUND_MAX);
-            p.round_events = tune_int("VR_TUNE_ROUND_EVENTS", span ? (ratio ? 16 : VR_ROUND_EVENTS) : 2 * VR_ROUND_EVENTS);
+            p.round_max = tuned(b->tune_round_max, span ? VR_ROUND_MAX : 2 * VR_ROUND_MAX);
+            p.round_events = tuned(b->tune_round_events, span ? (ratio ? 16 : VR_ROUND_EVENTS) : 2 * VR_ROUND_EVENTS);
             void (*kern)(const TrackParams);
             // empty-space runs read the skip grid, whose empty voxels only keep the sign of sigma for
             // multipliers >= 0 (the shadow multiplier is only read by the ratio tracker)
@@ -701,11 +747,11 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             // enough that the last chunks balance and that all waves stay on the same few image rows
             // (measured: 64-128 best on every workload, 2048 costs 8 % in L2 locality)
             const uint64_t fair = work.nitems / ((uint64_t)blocks * 4 * 8);
-            p.work.chunk = (uint32_t)std::min<uint64_t>((uint64_t)tune_int("VR_TUNE_CHUNK", 128), std::max<uint64_t>(64, fair & ~63ull));
-            HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
+            p.work.chunk = (uint32_t)std::min<uint64_t>((uint64_t)tuned(b->tune_chunk, 128), std::max<uint64_t>(64, fair & ~63ull));
+            if (timed) HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
             HIP_TRY(b, hipGetLastError());
-            HIP_TRY(b, hipEventRecord(ev.e1, b->stream));
+            if (timed) HIP_TRY(b, hipEventRecord(ev.e1, b->stream));
         } else {
             MarchParams p{};
             p.cam = cam; p.work = work;
@@ -730,20 +776,20 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             if (rc) return rc;
             // 8x8 over consecutive rows; 16x4 over a rank's share of interleaved rows, which is more compact in the
             // image (config 5, rank 3 of 8: 17.3 / 16.2 ms against 17.8 / 16.6 ms for 8x8; whole frame: 8x8 by 2 %)
-            p.tile_h_log = (uint32_t)tune_int("VR_TUNE_MARCH_TILE_H_LOG", cam.row_stride >= 4 ? 2 : 3);
+            p.tile_h_log = (uint32_t)(b->tune_march_tile_h_log > 0 ? b->tune_march_tile_h_log - 1 : (cam.row_stride >= 4 ? 2 : 3));
             if (p.tile_h_log > 6) return fail(b, VR_ERR_INVALID_ARG, "VR_TUNE_MARCH_TILE_H_LOG must be in [0, 6]");
             const uint64_t mtw = 64u >> p.tile_h_log, mth = 1u << p.tile_h_log;
             const uint64_t ntiles = ((cam.width + mtw - 1) / mtw) * ((cam.nrows + mth - 1) / mth) * sc;
             if (ntiles * 64u >= (1ull << 32)) return fail(b, VR_ERR_INVALID_ARG, "row set too large for one pass");
             p.work.nitems = (uint32_t)(ntiles * 64u);
             const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_cu * b->num_cu, (ntiles + 3) / 4));
-            HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
+            if (timed) HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
             HIP_TRY(b, hipGetLastError());
-            HIP_TRY(b, hipEventRecord(ev.e1, b->stream));
+            if (timed) HIP_TRY(b, hipEventRecord(ev.e1, b->stream));
         }
         const uint32_t nchan = (uint32_t)(npix * 3);
-        vr_resolve_kernel<<<(nchan + 255) / 256, 256, 0, b->stream>>>(b->d_samples, d_out, (uint32_t)npix, sc, s0 == 0 ? 1 : 0,
+        vr_resolve_kernel<<<(nchan + 255) / 256, 256, 0, b->stream>>>(d_samples, d_out, (uint32_t)npix, sc, s0 == 0 ? 1 : 0,
                                                                       s0 + sc >= spp ? 1 : 0, (float)spp);
         HIP_TRY(b, hipGetLastError());
     }
@@ -789,8 +835,8 @@ int vr_backend_create(int device, vr_backend** out)
     vr_backend* b = new vr_backend;
     b->device = device;
     auto bail = [&](const char* what, hipError_t err) {
-        int code = fail(nullptr, VR_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
-        delete b;
+        int code = fail(nullptr, err == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+        vr_backend_destroy(b);   // frees the stream and whatever was allocated so far
         return code;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
@@ -948,7 +994,8 @@ int vr_backend_set_mesh(vr_backend* b, const vr_mesh_desc* m)
     }
     std::vector<TreeNode> tree;
     std::vector<uint32_t> order;
-    build_bvh(bt, 0, m->ntris, tree, order);
+    read_knobs(b);
+    build_bvh(bt, 0, m->ntris, tree, order, (uint32_t)(b->tune_bvh_leaf > 0 ? b->tune_bvh_leaf : 1));
     std::vector<BvhNode>  nodes;                         // 8 layouts of tree.size() nodes each
     for (int octant = 0; octant < 8; ++octant) thread_bvh(tree, 0, octant, nodes, nodes.size());
     std::vector<TriDev> tris(order.size());
@@ -1034,7 +1081,7 @@ int vr_backend_last_stats(vr_backend* b, vr_render_stats* stats, float* kernel_m
         total += ms;
     }
     if (kernel_ms) *kernel_ms = total;
-    if (launches) *launches = (uint32_t)b->passes_used;
+    if (launches) *launches = b->launches;
     return VR_OK;
 }
 

@@ -797,7 +797,7 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
     constexpr bool IMPROVED = KIND == MARCH_IMPROVED;
     unsigned long long n_lookups = 0;
     const uint32_t k0 = p.work.key0, k1 = p.work.key1;
-    uint32_t n_queries = 0, n_light = 0, n_paths = 0;
+    uint32_t n_queries = 0, n_light = 0, n_paths = 0, n_guard = 0;
     // a wave takes an 8x8-pixel tile (p.work.nitems counts whole tiles): its 64 rays visit nearly the same BVH nodes
     // and triangles, which a wave executes as the union over its lanes (+10-17 % against 64 pixels of a row)
     // (the tile is (64 >> tile_h_log) x (1 << tile_h_log) pixels of the row set: flatter when the rows are a rank's
@@ -827,7 +827,8 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
         uint32_t depth = 0;
 
         // castRay + handleIntersection, recursion unrolled  IntegratorHomogeneousRayMarcherNEE.cpp:10-118
-        for (int guard = 0; guard < 4096; ++guard) {
+        int guard = 0;
+        for (; guard < 4096; ++guard) {
             if (depth >= p.max_depth) { result = mk3(0, 0, 0); break; }         // :12-14
             float tfar;
             n_queries++;
@@ -971,10 +972,13 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
             result = mk3(0, 0, 0);   // the reference falls off a non-void function here (:118): black
             break;
         }
+        if (guard == 4096) n_guard++;   // where the reference would still recurse: the sample stays black and is reported
         store_sample(p.work.samples, item, result);
     }
     unsigned long long a = wave_sum(n_paths), b = wave_sum(n_queries), c = wave_sum(n_light), e = wave_sum(n_lookups);
+    const unsigned long long gh = wave_sum(n_guard);
     if ((threadIdx.x & 63) == 0) {
+        if (gh) atomicAdd(&p.work.counters->step_limit_hits, gh);
         atomicAdd(&p.work.counters->path_samples, a);
         atomicAdd(&p.work.counters->ray_queries, b);
         atomicAdd(&p.work.counters->shadow_rays, c);
