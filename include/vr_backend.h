@@ -108,6 +108,24 @@ int vr_backend_render_row_set_device(vr_backend* b, const vr_options_pod* o, int
                                      void* d_rgb);
 int vr_backend_synchronize(vr_backend* b);
 
+/* vr_backend_render_row_set_device for callers that cannot allocate.  NO COUNTERPART IN THE
+ * REFERENCE: it exists for callers that cannot call hipMalloc — code under HIP graph capture,
+ * tight serving loops, harnesses that forbid allocation.  Same arguments, same frame (bit for bit)
+ * and same asynchrony as vr_backend_render_row_set_device, but the call allocates and frees
+ * nothing, creates no event and copies nothing from host memory: work counters, statistics
+ * counters, the trackers' parameter block, the sub-sample offsets and the per-sample staging
+ * buffer all live in one static device array of 129 MiB that every GPU the library runs on holds
+ * until the process ends.  Limits (VR_ERR_INVALID_ARG with a message beyond them):
+ * row_count*width <= 11 184 810 pixels per call (128 MiB of staging / 12 B; a 4K frame is 8.3 M
+ * pixels; more sub-samples than fit are rendered in several passes) and rayPerPixelCount <= 65 536.
+ * Every call on one GPU shares that GPU's array — also calls on different vr_backend handles — so
+ * calls that overlap on one GPU race: wait (vr_backend_synchronize) for one before issuing the
+ * next from another handle; calls on one handle are ordered by its stream.  No kernel time is
+ * measured (vr_backend_last_stats reports the counters and kernel_ms = 0). */
+int vr_backend_render_row_set_device_noalloc(vr_backend* b, const vr_options_pod* o, int integrator,
+                                             uint32_t row_first, uint32_t row_stride, uint32_t row_count,
+                                             void* d_rgb);
+
 /* Counters of the last render call (vr_types.h) and the HIP-event time of its integrator
  * kernel launches in milliseconds (sum over passes), measured on the backend's stream. */
 int vr_backend_last_stats(vr_backend* b, vr_render_stats* stats, float* kernel_ms, uint32_t* kernel_launches);

@@ -25,6 +25,7 @@ EXPORTS = [
     "vr_backend_set_mode", "vr_backend_set_seed", "vr_backend_set_sample_buffer_bytes", "vr_backend_render_rows",
     "vr_backend_render", "vr_backend_render_row_set_device", "vr_backend_synchronize", "vr_backend_last_stats",
     "vr_backend_tonemap_device", "vr_backend_max_channel_device", "vr_rgb_to_u8", "vr_abi_sizes",
+    "vr_backend_render_row_set_device_noalloc",
 ]
 
 
@@ -84,6 +85,7 @@ def lib():
     L.vr_backend_render_rows.argtypes = [vp, C.POINTER(OptionsPod), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
     L.vr_backend_render.argtypes = [vp, C.POINTER(OptionsPod), C.c_int, C.POINTER(C.c_float)]
     L.vr_backend_render_row_set_device.argtypes = [vp, C.POINTER(OptionsPod), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.vr_backend_render_row_set_device_noalloc.argtypes = L.vr_backend_render_row_set_device.argtypes
     L.vr_backend_synchronize.argtypes = [vp]
     L.vr_backend_last_stats.argtypes = [vp, C.POINTER(RenderStats), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.vr_backend_tonemap_device.argtypes = [vp, vp, C.c_uint64, C.c_float, C.POINTER(C.c_float)]
@@ -202,6 +204,12 @@ class Backend:
         self._check(self._L.vr_backend_render_row_set_device(self._h, C.byref(opts), integrator_id(integrator),
                                                              int(row_first), int(row_stride), int(row_count),
                                                              C.c_void_p(int(device_ptr))))
+
+    def render_row_set_device_noalloc(self, opts, integrator, row_first, row_stride, row_count, device_ptr):
+        """The same frame with every scratch buffer taken from the library's static device array: no allocation."""
+        self._check(self._L.vr_backend_render_row_set_device_noalloc(self._h, C.byref(opts), integrator_id(integrator),
+                                                                     int(row_first), int(row_stride), int(row_count),
+                                                                     C.c_void_p(int(device_ptr))))
 
     def synchronize(self):
         self._check(self._L.vr_backend_synchronize(self._h))

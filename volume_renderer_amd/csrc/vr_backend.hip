@@ -214,6 +214,25 @@ __global__ void k_store_cold(const TrackCold c, TrackCold* __restrict__ dst)
     if (threadIdx.x == 0 && blockIdx.x == 0) *dst = c;
 }
 
+// ---------------------------------------------------------------------------------------------
+// scratch of the allocation-free entry point (vr_backend_render_row_set_device_noalloc)
+// ---------------------------------------------------------------------------------------------
+// One array per GPU for the life of the process: work counters, statistics counters, the cold parameter block,
+// the sub-sample offsets and the per-sample staging buffer of ONE launch.  In host code the name is a stand-in,
+// not an address: vr_backend_create takes its address on the backend's device with hipGetSymbolAddress and
+// everything after that uses the pointer.
+#define VR_NOALLOC_HEADER_BYTES  (1u << 20)                     // counters, cold block, offsets of <= 65 536 sub-samples
+#define VR_NOALLOC_SAMPLE_BYTES  (128ull << 20)                 // staging of one sample pass: <= 11 184 810 pixels per row set
+#define VR_NOALLOC_MAX_SPP       65536u
+#define VR_NOALLOC_OFF_WORK      0u
+#define VR_NOALLOC_OFF_COUNTERS  256u
+#define VR_NOALLOC_OFF_COLD      1024u
+#define VR_NOALLOC_OFF_OFFSETS   (512u << 10)
+static __device__ __align__(256) unsigned char scratch[VR_NOALLOC_HEADER_BYTES + VR_NOALLOC_SAMPLE_BYTES];
+static_assert(VR_NOALLOC_OFF_COLD + sizeof(TrackCold) <= VR_NOALLOC_OFF_OFFSETS, "cold block overlaps the offsets");
+static_assert(VR_NOALLOC_OFF_OFFSETS + VR_NOALLOC_MAX_SPP * sizeof(float2) <= VR_NOALLOC_HEADER_BYTES, "offsets overlap the samples");
+static_assert(sizeof(Counters) <= VR_NOALLOC_OFF_COLD - VR_NOALLOC_OFF_COUNTERS, "counters overlap the cold block");
+
 struct Pass { hipEvent_t e0, e1; };
 
 } // namespace
@@ -253,6 +272,11 @@ struct vr_backend {
     size_t            passes_used = 0;
     uint32_t          launches = 0;           // integrator kernel launches of the last render call
     vr_render_stats   stats{};
+    Counters*         last_counters = nullptr; // where the last render call counted (d_counters or the no-alloc scratch)
+
+    // this device's copy of `scratch` (hipGetSymbolAddress at create)
+    unsigned char*    d_noalloc = nullptr;
+
     // developer knobs (VR_TUNE_*), read at the start of each render call; 0 = built-in default
     int tune_tile_h_log = 0, tune_round_max = 0, tune_round_events = 0, tune_chunk = 0, tune_march_tile_h_log = 0, tune_bvh_leaf = 0;
     // hipOccupancyMaxActiveBlocksPerMultiprocessor per kernel, asked once
@@ -571,8 +595,10 @@ int launch_cap(vr_backend* b, K kernel, const P&, int& blocks_per_cu)
     return VR_OK;
 }
 
+// noalloc: the allocation-free variant — every scratch buffer comes from this device's copy of `scratch`, nothing is
+// allocated or freed, no event is created (so no kernel time is reported) and nothing is copied from host memory.
 int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint32_t row_first, uint32_t row_stride,
-                   uint32_t row_count, float* d_out)
+                   uint32_t row_count, float* d_out, bool noalloc)
 {
     int rc = use_device(b);
     if (rc) return rc;
@@ -592,7 +618,17 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
     const uint32_t spp = o->rayPerPixelCount;
     const uint64_t npix = (uint64_t)row_count * o->width;
     if (npix * 3 >= (1ull << 32)) return fail(b, VR_ERR_INVALID_ARG, "row set too large");
-    const uint64_t budget = b->sample_budget;
+    const uint64_t budget = noalloc ? VR_NOALLOC_SAMPLE_BYTES : b->sample_budget;
+    if (noalloc) {
+        if (!b->d_noalloc) return fail(b, VR_ERR_HIP, "the scratch array of the allocation-free entry point was not resolved at create");
+        if (npix * 12 > VR_NOALLOC_SAMPLE_BYTES)
+            return fail(b, VR_ERR_INVALID_ARG, "row set of %llu pixels needs %llu bytes per sample pass; the allocation-free entry point "
+                        "holds %llu (at most %llu pixels per call): render fewer rows per call",
+                        (unsigned long long)npix, (unsigned long long)(npix * 12), (unsigned long long)VR_NOALLOC_SAMPLE_BYTES,
+                        (unsigned long long)(VR_NOALLOC_SAMPLE_BYTES / 12));
+        if (spp > VR_NOALLOC_MAX_SPP)
+            return fail(b, VR_ERR_INVALID_ARG, "rayPerPixelCount %u above the %u the allocation-free entry point holds offsets for", spp, VR_NOALLOC_MAX_SPP);
+    }
     uint64_t per_pass = std::max<uint64_t>(1, budget / (npix * 12));
     per_pass = std::min<uint64_t>(per_pass, spp);
     // The trackers hand out work tiles of 64 pixels, 8x8 over the row set, and their item space is padded to whole
@@ -606,22 +642,32 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
     per_pass = std::min<uint64_t>(per_pass, std::max<uint64_t>(1, 0x7fffffffull / npix_tiled));
     if (npix_tiled * per_pass >= (1ull << 31)) return fail(b, VR_ERR_INVALID_ARG, "row set too large for one pass");
 
-    // the staging buffer grows to what the frame needs; when HBM does not have it (other users of the GPU, a
-    // smaller device) render in more passes rather than fail
-    for (;;) {
-        rc = ensure(b, b->d_samples, b->samples_cap, (size_t)(npix * per_pass * 3));
-        if (rc != VR_ERR_OUT_OF_MEMORY || per_pass == 1) break;
-        (void)hipGetLastError();
-        per_pass = (per_pass + 1) / 2;
+    // scratch of this call
+    float*     d_samples;
+    float2*    d_offsets;
+    uint32_t*  d_work;
+    Counters*  d_counters;
+    TrackCold* d_cold;
+    if (noalloc) {
+        d_work = (uint32_t*)(b->d_noalloc + VR_NOALLOC_OFF_WORK);
+        d_counters = (Counters*)(b->d_noalloc + VR_NOALLOC_OFF_COUNTERS);
+        d_cold = (TrackCold*)(b->d_noalloc + VR_NOALLOC_OFF_COLD);
+        d_offsets = (float2*)(b->d_noalloc + VR_NOALLOC_OFF_OFFSETS);
+        d_samples = (float*)(b->d_noalloc + VR_NOALLOC_HEADER_BYTES);
+    } else {
+        // the staging buffer grows to what the frame needs; when HBM does not have it (other users of the GPU, a
+        // smaller device) render in more passes rather than fail
+        for (;;) {
+            rc = ensure(b, b->d_samples, b->samples_cap, (size_t)(npix * per_pass * 3));
+            if (rc != VR_ERR_OUT_OF_MEMORY || per_pass == 1) break;
+            (void)hipGetLastError();
+            per_pass = (per_pass + 1) / 2;
+        }
+        if (rc) return rc;
+        rc = ensure(b, b->d_offsets, b->offsets_cap, (size_t)spp);
+        if (rc) return rc;
+        d_work = b->d_work; d_counters = b->d_counters; d_cold = b->d_cold; d_offsets = b->d_offsets; d_samples = b->d_samples;
     }
-    if (rc) return rc;
-    rc = ensure(b, b->d_offsets, b->offsets_cap, (size_t)spp);
-    if (rc) return rc;
-    uint32_t* const  d_work = b->d_work;
-    Counters* const  d_counters = b->d_counters;
-    TrackCold* const d_cold = b->d_cold;
-    float2* const    d_offsets = b->d_offsets;
-    float* const     d_samples = b->d_samples;
     cam.offsets = d_offsets;
     k_quadrant_offsets<<<(spp + 255) / 256 > 256 ? 256 : (spp + 255) / 256, 256, 0, b->stream>>>(d_offsets, spp);
     HIP_TRY(b, hipGetLastError());
@@ -637,10 +683,11 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
     work.step_limit = 1u << 28;
 
     HIP_TRY(b, hipMemsetAsync(d_counters, 0, sizeof(Counters), b->stream));
+    b->last_counters = d_counters;
     b->passes_used = 0;
     b->launches = 0;
     const bool exact = b->mode != VR_MODE_FAST;
-    const bool timed = true;
+    const bool timed = !noalloc;
 
     for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)per_pass) {
         const uint32_t sc = (uint32_t)std::min<uint64_t>(per_pass, spp - s0);
@@ -800,7 +847,7 @@ int collect(vr_backend* b)
 {
     HIP_TRY(b, hipStreamSynchronize(b->stream));
     Counters c{};
-    HIP_TRY(b, hipMemcpy(&c, b->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    HIP_TRY(b, hipMemcpy(&c, b->last_counters ? b->last_counters : b->d_counters, sizeof c, hipMemcpyDeviceToHost));
     b->stats.path_samples = c.path_samples; b->stats.density_lookups = c.density_lookups;
     b->stats.scatter_events = c.scatter_events; b->stats.shadow_rays = c.shadow_rays;
     b->stats.ray_queries = c.ray_queries; b->stats.step_limit_hits = c.step_limit_hits;
@@ -849,6 +896,8 @@ int vr_backend_create(int device, vr_backend** out)
     if ((e = hipMalloc((void**)&b->d_maxbits, 256)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&b->d_cold, sizeof(TrackCold))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(b->d_counters, 0, sizeof(Counters))) != hipSuccess) return bail("hipMemset", e);
+    // this device's copy of the allocation-free entry point's scratch array (each GPU holds its own, at its own address)
+    if ((e = hipGetSymbolAddress((void**)&b->d_noalloc, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     *out = b;
     return VR_OK;
 }
@@ -1030,7 +1079,14 @@ int vr_backend_render_row_set_device(vr_backend* b, const vr_options_pod* o, int
                                      uint32_t row_stride, uint32_t row_count, void* d_rgb)
 {
     if (!b) return VR_ERR_INVALID_ARG;
-    return render_row_set(b, o, integrator, row_first, row_stride, row_count, (float*)d_rgb);
+    return render_row_set(b, o, integrator, row_first, row_stride, row_count, (float*)d_rgb, false);
+}
+
+int vr_backend_render_row_set_device_noalloc(vr_backend* b, const vr_options_pod* o, int integrator, uint32_t row_first,
+                                             uint32_t row_stride, uint32_t row_count, void* d_rgb)
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    return render_row_set(b, o, integrator, row_first, row_stride, row_count, (float*)d_rgb, true);
 }
 
 int vr_backend_synchronize(vr_backend* b)
@@ -1054,7 +1110,7 @@ int vr_backend_render_rows(vr_backend* b, const vr_options_pod* o, int integrato
     const size_t   nfl = (size_t)rows * o->width * 3;
     rc = ensure(b, b->d_rows, b->rows_cap, nfl);
     if (rc) return rc;
-    rc = render_row_set(b, o, integrator, from_row - o->heightStartOffset, 1, rows, b->d_rows);
+    rc = render_row_set(b, o, integrator, from_row - o->heightStartOffset, 1, rows, b->d_rows, false);
     if (rc) return rc;
     HIP_TRY(b, hipMemcpyAsync(pix, b->d_rows, nfl * sizeof(float), hipMemcpyDeviceToHost, b->stream));
     return collect(b);
