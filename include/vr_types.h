@@ -26,7 +26,11 @@ typedef enum vr_integrator_id {
     VR_INTEGRATOR_NANOVDB_EMISSION                 = 5, /* "nanoVDBEmission"               */
     VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE       = 6, /* "heterogeneousPerlinNoise"      */
     VR_INTEGRATOR_DENSITY_SAMPLING                 = 7, /* "densitySampling"               */
-    VR_INTEGRATOR_COUNT                            = 8
+    /* No reference counterpart (its trackers clip to the grid bbox only, IntegratorDeltaTracking.cpp:37-39):
+     * the trackers with their walk cut to the mesh's entry/exit interval — SURVEY 8(d) config 5. */
+    VR_INTEGRATOR_MESH_RATIO_TRACKING              = 8, /* "meshRatioTracking"             */
+    VR_INTEGRATOR_MESH_DELTA_TRACKING              = 9, /* "meshDeltaTracking"             */
+    VR_INTEGRATOR_COUNT                            = 10
 } vr_integrator_id;
 
 /* POD mirror of `struct Options` (Utils/Types.h:85-122) without the strings/vectors.

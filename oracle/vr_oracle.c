@@ -828,6 +828,59 @@ typedef struct path_ctx {
 
 static inline v3 opt3(const float* p) { return v3_make(p[0], p[1], p[2]); }
 
+/* ------------------------------------------------------------------------------------ */
+/* mesh-bounded media for the trackers — NO REFERENCE COUNTERPART                        */
+/* ------------------------------------------------------------------------------------ */
+/* The reference's trackers clip to the grid bbox only (REF IntegratorDeltaTracking.cpp:37-39,
+ * IntegratorRatioTracking.cpp:37-39); SURVEY 8(d) config 5 defines the capability: the walk's
+ * segment is the bbox interval cut by the mesh's entry/exit interval.  Entry and exit are found
+ * by the walk the reference's MARCHERS do before they march (REF
+ * IntegratorHomogeneousRayMarcherNEE.cpp:16-60, 104-108): closest hit; a hit on another object
+ * than the last one is an entry and moves the origin to hit + dir * 0.001; the next hit on the
+ * same object is the exit.  A ray that starts inside a medium (scattered rays, shadow rays)
+ * starts with that medium's object as "the last one", so its first hit on it is the exit.
+ * Opaque shapes (dissolve <= 0) are black absorbers (the marchers return black there).
+ * Returns the interval [*s0, *s1] in units of |dir| from `org`. */
+enum { SEG_NONE = 0, SEG_FOUND = 1, SEG_BLACK = 2 };
+static int mesh_segment(path_ctx* d, v3 org, v3 dir, int inside_id, float* s0, float* s1, int* medium)
+{
+    const vr_mesh_desc* m = d->sc->mesh;
+    int object = inside_id;
+    float s_acc = 0.0f, start = 0.0f;
+    for (int guard = 0; guard < 64; ++guard) {
+        float o3[3] = { org.x, org.y, org.z }, d3[3] = { dir.x, dir.y, dir.z }, t;
+        d->st->ray_queries++;
+        int prim = vro_intersect_closest(m, o3, d3, &t);                    /* REF EmbreeHelper.cpp:18 */
+        if (prim < 0) return SEG_NONE;
+        int previous = object;                                              /* REF :24 */
+        object = (int)m->prim_to_shape[prim];                               /* REF :27 */
+        if (!(m->shape_dissolve[object] > 0)) return SEG_BLACK;             /* REF NEE.cpp:52, :118 */
+        if (previous == object) {                                           /* REF NEE.cpp:55 exit hit */
+            *s0 = start; *s1 = s_acc + t; *medium = object;
+            return SEG_FOUND;
+        }
+        v3 hit = v3_add(v3_scale(dir, t), org);                             /* REF EmbreeHelper.cpp:28 */
+        org = v3_add(hit, v3_scale(dir, 0.001f));                           /* REF NEE.cpp:105 */
+        s_acc = (s_acc + t) + 0.001f;
+        start = s_acc;
+    }
+    return SEG_NONE;
+}
+/* cut the index-space ray by the mesh interval of the matching world-space ray; scale = index
+ * parameter per world parameter.  Returns SEG_*; SEG_FOUND with an empty interval sets *empty. */
+static int mesh_clip(path_ctx* d, iray* r, v3 worg, v3 wdir, float scale, int inside_id, int* medium, int* empty)
+{
+    float s0 = 0, s1 = 0;
+    *empty = 0;
+    int rc = mesh_segment(d, worg, wdir, inside_id, &s0, &s1, medium);
+    if (rc != SEG_FOUND) return rc;
+    float a = s0 * scale, b = s1 * scale;
+    if (a > r->t0) r->t0 = a;
+    if (b < r->t1) r->t1 = b;
+    if (r->t0 > r->t1) *empty = 1;
+    return rc;
+}
+
 /* Safety cap (not in the reference, which would spin forever): a path whose t stops
  * advancing is cut and counted in stats->step_limit_hits. */
 #define VRO_STEP_LIMIT 200000000ull
@@ -835,7 +888,7 @@ static inline v3 opt3(const float* p) { return v3_make(p[0], p[1], p[2]); }
 /* ------------------------------------------------------------------------------------ */
 /* delta tracking (REF integrators/IntegratorDeltaTracking.cpp:11-176)                   */
 /* ------------------------------------------------------------------------------------ */
-static v3 cast_ray_delta(path_ctx* d)
+static v3 cast_ray_delta(path_ctx* d, int mesh_bound)
 {
     const vr_options_pod* o = d->o;
     const vr_grid_desc* grid = d->sc->density;
@@ -848,6 +901,14 @@ static v3 cast_ray_delta(path_ctx* d)
 
     iray iRay = ray_world_to_index(grid, d->rayOrigin, d->rayDirection);    /* :30-35 */
     if (!ray_clip(&iRay, grid)) return opt3(o->backgroundColor);           /* :37-39 */
+    int medium = -1;
+    if (mesh_bound) {   /* no reference counterpart: see mesh_segment */
+        v3 idir = mat_mult(grid->inv_mat, d->rayDirection);
+        float length = sqrtf(idir.x * idir.x + idir.y * idir.y + idir.z * idir.z);   /* as Ray.h:262-266 scales t0 */
+        int empty, rc = mesh_clip(d, &iRay, d->rayOrigin, d->rayDirection, length, -1, &medium, &empty);
+        if (rc == SEG_BLACK) return v3_make(0, 0, 0);
+        if (rc == SEG_NONE || empty) return opt3(o->backgroundColor);
+    }
 
     v3 result = v3_make(0, 0, 0);                                           /* :41 */
     float sigma_maj = d->sigma_max * (o->sigma_a + o->sigma_s);             /* :44-47 */
@@ -909,6 +970,11 @@ static v3 cast_ray_delta(path_ctx* d)
             d->rayDirection = scattered;                                    /* :146 */
             iRay = ray_make(iRayOrigin, scattered, 1e-5f, FLT_MAX);         /* :147 */
             if (!ray_clip(&iRay, grid)) { terminated = 1; break; }          /* :150-155 */
+            if (mesh_bound) {
+                int empty, rc = mesh_clip(d, &iRay, index_to_world(grid, iRayOrigin), mat_mult(grid->mat, scattered), 1.0f,
+                                          medium, &medium, &empty);
+                if (rc == SEG_BLACK || empty) { terminated = 1; break; }
+            }
             tFar = iRay.t0;                                                 /* :157 */
         }
     }
@@ -921,7 +987,7 @@ static v3 cast_ray_delta(path_ctx* d)
 /* ------------------------------------------------------------------------------------ */
 
 /* REF IntegratorRatioTracking.cpp:213-283 (maxStepSize and sigma_maj are unused there) */
-static float direct_lightning_ray_march(path_ctx* d, const iray* iRay)
+static float direct_lightning_ray_march(path_ctx* d, const iray* iRay, int mesh_bound, int medium)
 {
     const vr_options_pod* o = d->o;
     const vr_grid_desc* grid = d->sc->density;
@@ -934,6 +1000,13 @@ static float direct_lightning_ray_march(path_ctx* d, const iray* iRay)
     v3 lightDirection = opt3(o->lightPosition);                             /* :221-225 */
     iray lightRay = ray_make(ray_at(iRay, iRay->t0), lightDirection, 1e-5f, FLT_MAX); /* :226 */
     if (!ray_clip(&lightRay, grid)) return transmission;                   /* :229-232 */
+    if (mesh_bound) {
+        int empty, m2 = medium;
+        int rc = mesh_clip(d, &lightRay, index_to_world(grid, lightRay.eye), mat_mult(grid->mat, lightDirection), 1.0f,
+                           medium, &m2, &empty);
+        if (rc == SEG_BLACK) return 0.0f;          /* an opaque surface between the point and the light */
+        if (empty) return transmission;
+    }
     float tFar = lightRay.t0;                                               /* :234 */
     uint64_t steps = 0;
 
@@ -968,7 +1041,7 @@ static float direct_lightning_ray_march(path_ctx* d, const iray* iRay)
 }
 
 /* REF IntegratorRatioTracking.cpp:11-211 */
-static v3 cast_ray_ratio(path_ctx* d)
+static v3 cast_ray_ratio(path_ctx* d, int mesh_bound)
 {
     const vr_options_pod* o = d->o;
     const vr_grid_desc* grid = d->sc->density;
@@ -980,6 +1053,14 @@ static v3 cast_ray_ratio(path_ctx* d)
 
     iray iRay = ray_world_to_index(grid, d->rayOrigin, d->rayDirection);    /* :30-35 */
     if (!ray_clip(&iRay, grid)) return opt3(o->backgroundColor);           /* :37-39 */
+    int medium = -1;
+    if (mesh_bound) {   /* no reference counterpart: see mesh_segment */
+        v3 idir = mat_mult(grid->inv_mat, d->rayDirection);
+        float length = sqrtf(idir.x * idir.x + idir.y * idir.y + idir.z * idir.z);
+        int empty, rc = mesh_clip(d, &iRay, d->rayOrigin, d->rayDirection, length, -1, &medium, &empty);
+        if (rc == SEG_BLACK) return v3_make(0, 0, 0);
+        if (rc == SEG_NONE || empty) return opt3(o->backgroundColor);
+    }
 
     float sigma_maj = d->sigma_max * (o->sigma_a + o->sigma_s);             /* :42-45 */
     float tFar = iRay.t0;                                                   /* :48 */
@@ -1048,7 +1129,7 @@ static v3 cast_ray_ratio(path_ctx* d)
             d->st->scatter_events++;
             if (transmission > 0.0f) {                                      /* :141 */
                 rng_push_shadow(d->rng);
-                float lightTransmission = direct_lightning_ray_march(d, &iRay); /* :143 */
+                float lightTransmission = direct_lightning_ray_march(d, &iRay, mesh_bound, medium); /* :143 */
                 rng_pop_shadow(d->rng);
                 float cos_theta = u_dot(d->rayDirection, opt3(o->lightPosition)); /* :144 */
                 float hgPDF = hg_phase(o->heyneyGreensteinG, cos_theta);   /* :145 */
@@ -1067,7 +1148,12 @@ static v3 cast_ray_ratio(path_ctx* d)
                 }
                 d->rayDirection = scattered;                                /* :178 */
                 iRay = ray_make(iRayOrigin, scattered, 1e-5f, FLT_MAX);     /* :179 */
-                    if (!ray_clip(&iRay, grid)) { terminated = 1; break; }      /* :182-187 */
+                if (!ray_clip(&iRay, grid)) { terminated = 1; break; }      /* :182-187 */
+                if (mesh_bound) {
+                    int empty, rc = mesh_clip(d, &iRay, index_to_world(grid, iRayOrigin), mat_mult(grid->mat, scattered), 1.0f,
+                                              medium, &medium, &empty);
+                    if (rc == SEG_BLACK || empty) { terminated = 1; break; }
+                }
                 tFar = iRay.t0;                                             /* :189 */
             }
         }
@@ -1369,12 +1455,14 @@ static v3 cast_ray(path_ctx* d, int integrator)
     switch (integrator) {
     case VR_INTEGRATOR_HOMOGENEOUS_RAY_MARCHER_NEE:      return cast_ray_marcher(d, 0);
     case VR_INTEGRATOR_HOMOGENEOUS_RAY_MARCHER_IMPROVED: return cast_ray_marcher(d, 1);
-    case VR_INTEGRATOR_RATIO_TRACKING:                   return cast_ray_ratio(d);
+    case VR_INTEGRATOR_RATIO_TRACKING:                   return cast_ray_ratio(d, 0);
+    case VR_INTEGRATOR_MESH_RATIO_TRACKING:              return cast_ray_ratio(d, 1);
+    case VR_INTEGRATOR_MESH_DELTA_TRACKING:              return cast_ray_delta(d, 1);
     case VR_INTEGRATOR_NANOVDB_SIMPLE:                   return cast_ray_grid_marcher(d, 0);
     case VR_INTEGRATOR_NANOVDB_EMISSION:                 return cast_ray_grid_marcher(d, 1);
     case VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE:       return cast_ray_marcher(d, 2); /* same castRay walk (:12-60, :155-168) */
     case VR_INTEGRATOR_DENSITY_SAMPLING:                 return cast_ray_density_sampling(d);
-    default:                                             return cast_ray_delta(d);
+    default:                                             return cast_ray_delta(d, 0);
     }
 }
 
@@ -1382,6 +1470,10 @@ static int scene_ok(const vro_scene* sc, int integrator)
 {
     if (integrator < 0 || integrator >= VR_INTEGRATOR_COUNT) return VR_ERR_INVALID_ARG;
     if (integrator == VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE || integrator == VR_INTEGRATOR_DENSITY_SAMPLING) { if (!sc->mesh) return VR_ERR_NO_MESH; }
+    else if (integrator == VR_INTEGRATOR_MESH_RATIO_TRACKING || integrator == VR_INTEGRATOR_MESH_DELTA_TRACKING) {
+        if (!sc->density) return VR_ERR_NO_DENSITY;
+        if (!sc->mesh) return VR_ERR_NO_MESH;
+    }
     else if (integrator >= VR_INTEGRATOR_RATIO_TRACKING) {
         if (!sc->density) return VR_ERR_NO_DENSITY;
         if (integrator == VR_INTEGRATOR_NANOVDB_EMISSION && !sc->temperature) return VR_ERR_NO_DENSITY; /* Emission :13-18 exits */

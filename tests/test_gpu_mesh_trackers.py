@@ -1,0 +1,169 @@
+"""Mesh-bounded ratio / delta tracking (BASELINE config 5, tracker leg; VR_INTEGRATOR_MESH_*_TRACKING).
+
+The reference has no such integrator (its trackers clip to the grid bbox only, IntegratorDeltaTracking.cpp:37-39):
+the oracle restates the capability as SURVEY 8(d) config 5 defines it (oracle/vr_oracle.c, mesh_segment) and the HIP
+path must reproduce the oracle bit for bit in the exact modes — image, lookups, scatters, shadow rays and closest-hit
+queries — on a cube, an icosphere, two objects and the reference's own SphereOnly.obj / CornellBox-Sphere.obj
+(tests/golden/ref_models.npz: the arrays objloader reads from them).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import scenes
+from volume_renderer_amd import MODE_EXACT, MODE_EXACT_SKIP, MODE_FAST, Backend, Grid
+
+pytestmark = pytest.mark.gpu
+
+RATIO, DELTA, MESH_RATIO, MESH_DELTA = 2, 3, 8, 9
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_models.npz")
+COUNTS = ("path_samples", "density_lookups", "scatter_events", "shadow_rays", "ray_queries")
+
+
+def bitexact(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def backend():
+    b = Backend(0)
+    yield b
+    b.close()
+
+
+def cloud_over(oracle, n, extent, center):
+    vox = np.zeros((n, n, n), dtype=np.float32)
+    oracle.vro_make_cloud(n, scenes.cloud_radius(n), ol.fptr(vox), 8)
+    vs, origin = scenes.mesh_tracker_grid_map(n, extent, center)
+    return Grid(vox, voxel_size=vs, origin=origin)
+
+
+def oracle_image(oracle, scene, opts, integ):
+    oracle.vro_set_math_mode(ol.MATH_SHARED)
+    try:
+        return ol.render(scene, opts, integ, rng_mode=ol.RNG_PHILOX, seed=scenes.SEED, want_stats=True)
+    finally:
+        oracle.vro_set_math_mode(ol.MATH_LIBM)
+
+
+def scene_case(oracle, name):
+    """(mesh, grid, option overrides)"""
+    if name == "cube":
+        return scenes.cube_mesh(), cloud_over(oracle, 64, 6.4, (0.0, 0.5, 0.0)), {}
+    if name == "icosphere":
+        return scenes.icosphere_mesh(), cloud_over(oracle, 64, 6.4, (0.0, 0.5, 0.0)), {}
+    if name == "two_objects":
+        return scenes.two_object_mesh(), cloud_over(oracle, 64, 6.4, (0.0, 0.5, 0.0)), {}
+    if name == "sphere_only":
+        return scenes.reference_model("sphere_only", GOLDEN), cloud_over(oracle, 64, 6.4, (0.0, 0.5, 0.0)), {}
+    if name == "cornell_sphere":
+        # the box is [-1.02, 1] x [0, 1.59] x [-1.04, 0.99]; the grid spans 3.2 around its middle
+        return (scenes.reference_model("cornell_sphere", GOLDEN), cloud_over(oracle, 64, 3.2, (0.0, 0.8, 0.0)),
+                dict(cameraPosition=(0.0, 0.8, 3.6), fov=40.0))
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["cube", "icosphere", "two_objects", "sphere_only", "cornell_sphere"])
+@pytest.mark.parametrize("integ", [MESH_RATIO, MESH_DELTA])
+@pytest.mark.parametrize("regime", ["shipped", "textbook"])
+def test_mesh_trackers_exact_modes_are_bit_identical(backend, oracle, name, integ, regime):
+    mesh, grid, kw = scene_case(oracle, name)
+    o = scenes.options_mesh_tracker(integ, 64, 56, 48, 4, regime=regime, **kw)
+    sc, _ = ol.make_scene(density=grid, mesh=mesh)
+    want, wst = oracle_image(oracle, sc, o, integ)
+    backend.set_density(grid)
+    backend.set_mesh(mesh)
+    backend.set_seed(scenes.SEED)
+    for mode in (MODE_EXACT, MODE_EXACT_SKIP):
+        backend.set_mode(mode)
+        got = backend.render(o, integ)
+        st = backend.last_stats()
+        assert bitexact(got, want), f"mode {mode}: {np.count_nonzero(got.view(np.uint32) != want.view(np.uint32))} of {got.size} channels differ"
+        for k in COUNTS:
+            assert st[k] == wst[k], (mode, k)
+        assert st["step_limit_hits"] == 0
+    # the mesh does bound the medium: the unbounded tracker gives another image, and the walks did cross the medium
+    plain = backend.render(o, RATIO if integ == MESH_RATIO else DELTA)
+    assert not bitexact(plain, want)
+    assert wst["density_lookups"] > 4 * wst["path_samples"] and wst["ray_queries"] >= 56 * 48 * 4
+    bg = np.array(o.backgroundColor[:], dtype=np.float32)
+    assert 0.01 < np.mean(np.any(want != bg, axis=-1)) < 0.95     # medium pixels and background pixels both (delta: absorbed paths only)
+
+
+@pytest.mark.parametrize("integ", [MESH_RATIO, MESH_DELTA])
+def test_mesh_trackers_fast_mode_tracks_the_oracle(backend, oracle, integ):
+    mesh, grid, kw = scene_case(oracle, "sphere_only")
+    o = scenes.options_mesh_tracker(integ, 64, 64, 64, 16, regime="shipped", **kw)
+    sc, _ = ol.make_scene(density=grid, mesh=mesh)
+    want, wst = oracle_image(oracle, sc, o, integ)
+    backend.set_density(grid)
+    backend.set_mesh(mesh)
+    backend.set_seed(scenes.SEED)
+    backend.set_mode(MODE_FAST)
+    got = backend.render(o, integ)
+    st = backend.last_stats()
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    assert np.mean(np.all(rel < 1e-4, axis=-1)) > 0.80
+    assert abs(got.mean() - want.mean()) / want.mean() < 5e-3
+    assert abs(st["density_lookups"] - wst["density_lookups"]) / wst["density_lookups"] < 5e-3
+    assert abs(st["ray_queries"] - wst["ray_queries"]) / wst["ray_queries"] < 5e-3
+
+
+def test_mesh_trackers_with_temperature_importance_sampling_crop_and_rotation(backend, oracle):
+    mesh, grid, _ = scene_case(oracle, "two_objects")
+    rng = np.random.default_rng(5)
+    temp = Grid((rng.uniform(0, 2, size=(40, 40, 40)) * (rng.uniform(size=(40, 40, 40)) < 0.5)).astype(np.float32),
+                bbox_min=(-20, -20, -20), voxel_size=0.1, origin=(0.0, 0.5, 0.0))
+    sc, _ = ol.make_scene(density=grid, temperature=temp, mesh=mesh)
+    backend.set_density(grid, temp)
+    backend.set_mesh(mesh)
+    backend.set_seed(scenes.SEED)
+    backend.set_mode(MODE_EXACT_SKIP)
+    for integ in (MESH_RATIO, MESH_DELTA):
+        for is_mode in (0, 1):
+            o = scenes.options_mesh_tracker(integ, 64, 40, 30, 4, regime="shipped", widthReference=96, heightReference=72,
+                                            widthStartOffset=28, heightStartOffset=20, cameraPosition=(2.5, 3.0, 6.0),
+                                            cameraRotation=(-20.0, 20.0, 3.0), emissionColor=(0.9, 0.4, 0.1),
+                                            mediumColor=(0.2, 0.3, 0.4), lightPosition=(0.3, 1.0, -0.2),
+                                            shadowRayDensityMultiplier=4.0, useImportanceSampling=is_mode)
+            want, wst = oracle_image(oracle, sc, o, integ)
+            got = backend.render(o, integ)
+            st = backend.last_stats()
+            assert bitexact(got, want), (integ, is_mode, np.count_nonzero(got != want))
+            for k in COUNTS:
+                assert st[k] == wst[k], (integ, is_mode, k)
+
+
+def test_mesh_trackers_opaque_shapes_absorb(backend, oracle):
+    """dissolve <= 0 (`d 0` in the .mtl): camera rays that meet the shape first are black, and it shadows the medium
+    behind it (the cube in front of the sphere is made opaque)."""
+    mesh = scenes.two_object_mesh()
+    mesh.shape_dissolve[0] = 0.0
+    grid = cloud_over(oracle, 64, 6.4, (0.0, 0.5, 0.0))
+    sc, _ = ol.make_scene(density=grid, mesh=mesh)
+    backend.set_density(grid)
+    backend.set_mesh(mesh)
+    backend.set_seed(scenes.SEED)
+    backend.set_mode(MODE_EXACT)
+    for integ in (MESH_RATIO, MESH_DELTA):
+        o = scenes.options_mesh_tracker(integ, 64, 48, 40, 4, lightPosition=(-0.5, 0.2, 1.0))
+        want, wst = oracle_image(oracle, sc, o, integ)
+        got = backend.render(o, integ)
+        assert bitexact(got, want)
+        assert backend.last_stats()["ray_queries"] == wst["ray_queries"]
+        assert np.mean(np.all(want == 0.0, axis=-1)) > 0.02        # the opaque cube's pixels
+
+
+def test_mesh_trackers_need_mesh_and_grid(oracle):
+    from volume_renderer_amd import BackendError
+    with Backend(0) as b:
+        o = scenes.options_mesh_tracker(MESH_DELTA, 64, 8, 8, 1)
+        with pytest.raises(BackendError) as e:
+            b.render(o, MESH_DELTA)
+        assert e.value.code == -4            # VR_ERR_NO_DENSITY
+        b.set_density(cloud_over(oracle, 16, 6.4, (0.0, 0.5, 0.0)))
+        with pytest.raises(BackendError) as e:
+            b.render(o, MESH_DELTA)
+        assert e.value.code == -5            # VR_ERR_NO_MESH

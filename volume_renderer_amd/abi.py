@@ -17,6 +17,9 @@ INTEGRATORS = {
     "nanoVDBEmission": 5,
     "heterogeneousPerlinNoise": 6,
     "densitySampling": 7,
+    # no reference counterpart: the trackers cut to the mesh's entry/exit interval
+    "meshRatioTracking": 8,
+    "meshDeltaTracking": 9,
 }
 
 VR_OK = 0

@@ -563,8 +563,11 @@ int validate(vr_backend* b, const vr_options_pod* o, int integrator)
         if (!b->has_density) return fail(b, VR_ERR_NO_DENSITY, "the grid marchers need a density grid (SceneLoader.cpp:212-213)");
         if (integrator == VR_INTEGRATOR_NANOVDB_EMISSION && !b->has_temperature)
             return fail(b, VR_ERR_NO_DENSITY, "nanoVDBEmission needs a temperature grid (IntegratorNanoVDBEmission.cpp:13-18 exits)");
-    } else if (integrator == VR_INTEGRATOR_RATIO_TRACKING || integrator == VR_INTEGRATOR_DELTA_TRACKING) {
+    } else if (integrator == VR_INTEGRATOR_RATIO_TRACKING || integrator == VR_INTEGRATOR_DELTA_TRACKING ||
+               integrator == VR_INTEGRATOR_MESH_RATIO_TRACKING || integrator == VR_INTEGRATOR_MESH_DELTA_TRACKING) {
         if (!b->has_density) return fail(b, VR_ERR_NO_DENSITY, "tracking integrators need a density grid (SceneLoader.cpp:212-213)");
+        if ((integrator == VR_INTEGRATOR_MESH_RATIO_TRACKING || integrator == VR_INTEGRATOR_MESH_DELTA_TRACKING) && !b->has_mesh)
+            return fail(b, VR_ERR_NO_MESH, "the mesh-bounded trackers need a mesh");
         // every step must advance t in float, or the reference's loops never end
         if (!(o->stepSizeMin > 0.0f) || !(o->stepSizeMax >= o->stepSizeMin))
             return fail(b, VR_ERR_INVALID_ARG, "stepSize min must be > 0 and <= max (the reference would not terminate)");
@@ -674,7 +677,8 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
 
     // the voxel-span / empty-run estimates assume ray parameters of at most a few thousand voxels
     bool span_ok = true;
-    const bool tracking = integrator == VR_INTEGRATOR_RATIO_TRACKING || integrator == VR_INTEGRATOR_DELTA_TRACKING;
+    const bool mesh_bound = integrator == VR_INTEGRATOR_MESH_RATIO_TRACKING || integrator == VR_INTEGRATOR_MESH_DELTA_TRACKING;
+    const bool tracking = integrator == VR_INTEGRATOR_RATIO_TRACKING || integrator == VR_INTEGRATOR_DELTA_TRACKING || mesh_bound;
     if (tracking) span_ok = tracking_t_max(b, o) < 8000.0f;
 
     WorkDev work{};
@@ -745,6 +749,11 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             cold.tile_h_log = (uint32_t)tile_h_log;
             work.nitems = (uint32_t)(npix_tiled * sc);
             cold.temperature = b->tgrid;
+            if (mesh_bound) {
+                cold.mesh.nodes = b->d_nodes; cold.mesh.tris = b->d_tris; cold.mesh.prim_to_shape = b->d_p2s;
+                cold.mesh.shape_dissolve = b->d_dissolve; cold.mesh.shape_diffuse = b->d_diffuse; cold.mesh.nnodes = b->nnodes;
+                memcpy(cold.mat, b->mat, sizeof cold.mat);
+            }
             k_store_cold<<<1, 64, 0, b->stream>>>(cold, d_cold);
             HIP_TRY(b, hipGetLastError());
             TrackParams p{};
@@ -763,7 +772,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 const float typical = std::min(std::max(o->stepSizeMin, mean_free), o->stepSizeMax);
                 span = typical < 0.25f && span_ok;
             }
-            const bool ratio = integrator == VR_INTEGRATOR_RATIO_TRACKING;
+            const bool ratio = integrator == VR_INTEGRATOR_RATIO_TRACKING || integrator == VR_INTEGRATOR_MESH_RATIO_TRACKING;
             // a round of the step loop ends after round_max trips or when round_events lanes wait for the
             // event phase (measured per regime: sub-voxel steps have long trips and rare events, voxel-sized
             // steps one iteration per trip and an event every few iterations)
@@ -774,8 +783,9 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             // multipliers >= 0 (the shadow multiplier is only read by the ratio tracker)
             const bool skip_ok = span_ok && o->lightRayDensityMultiplier >= 0.0f && (!ratio || o->shadowRayDensityMultiplier >= 0.0f);
             if (skip_ok && b->mode != VR_MODE_EXACT) p.density.bricks = b->d_skip;
-#define VR_TK4(I, E, S, Q) (temp ? (span ? vr_track_kernel<I, E, S, Q, true, true> : vr_track_kernel<I, E, S, Q, true, false>) \
-                                 : (span ? vr_track_kernel<I, E, S, Q, false, true> : vr_track_kernel<I, E, S, Q, false, false>))
+#define VR_TK5(I, E, S, Q, T, N) (mesh_bound ? vr_track_kernel<I, E, S, Q, T, N, true> : vr_track_kernel<I, E, S, Q, T, N, false>)
+#define VR_TK4(I, E, S, Q) (temp ? (span ? VR_TK5(I, E, S, Q, true, true) : VR_TK5(I, E, S, Q, true, false)) \
+                                 : (span ? VR_TK5(I, E, S, Q, false, true) : VR_TK5(I, E, S, Q, false, false)))
 #define VR_TRACK_KERNEL(E, S) (ratio ? (is ? VR_TK4(INTEG_RATIO, E, S, true) : VR_TK4(INTEG_RATIO, E, S, false)) \
                                      : (is ? VR_TK4(INTEG_DELTA, E, S, true) : VR_TK4(INTEG_DELTA, E, S, false)))
             switch (skip_ok ? b->mode : (b->mode == VR_MODE_FAST ? -1 : VR_MODE_EXACT)) {
@@ -784,6 +794,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             case VR_MODE_EXACT_SKIP: kern = VR_TRACK_KERNEL(true, true); break;
             default:                 kern = VR_TRACK_KERNEL(false, true); break;
             }
+#undef VR_TK5
 #undef VR_TK4
 #undef VR_TRACK_KERNEL
             int per_cu = 4;

@@ -58,31 +58,6 @@ struct WorkDev {
     uint32_t           step_limit;
 };
 
-// Parameters only the event phases read (path set-up, scatter, shadow start/end).  They live in
-// device memory and are read with ordinary loads there, so that they do not occupy scalar
-// registers across the step loop.
-struct TrackCold {
-    CameraDev cam;
-    float     inv_mat[9], vec[3];
-    float     bmin[3], bmax1[3];     // float(bbox.min), float(bbox.max + 1)
-    float     g;
-    float     light[3], light_color[3];
-    float     emission[3], medium[3], background[3];
-    uint32_t  max_depth;
-    uint32_t  tile_h_log;           // work tiles are (64 >> tile_h_log) columns x (1 << tile_h_log) rows of the row set
-    GridDev   temperature;
-};
-// Kernel argument: what the step loop reads.
-struct TrackParams {
-    const TrackCold* cold;
-    WorkDev   work;
-    GridDev   density;               // SKIP kernels: the skip grid (empty voxels hold -(empty-cube radius + 1))
-    int32_t   round_max, round_events; // step-loop trips per round / waiting lanes that end a round early
-    float     sigma_a, sigma_s, sigma_maj;
-    float     t_min, t_max, step_mult;
-    float     light_mult, shadow_mult;
-};
-
 // primary ray of (abs column i, abs row j, sub-sample s)                  BaseIntegrator.cpp:35-64
 // EXACT: the reference's arithmetic (x and y in double, correctly rounded normalisation); otherwise the same
 // formula in float with a hardware reciprocal square root — one ulp on a direction, for the FAST trackers only
@@ -124,6 +99,164 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
     }
     return v;
 }
+
+// =============================================================================================
+// closest hit over the mesh (stand-in for rtcIntersect1)
+// =============================================================================================
+// Threaded BVH in depth-first order: a node that is hit continues at node+1 (its first child, or
+// for a leaf the next subtree), a node that is missed continues at `skip`.  No stack.  MeshDev::nodes
+// holds eight such layouts of the same tree, one per sign octant of the ray direction, each visiting
+// the child nearer to its rays first.
+struct BvhNode {
+    float    lo[3], hi[3];
+    uint32_t skip;
+    uint32_t first, count;   // leaf: triangles [first, first+count); inner: count = 0
+};
+struct TriDev {
+    float    v0[3], e1[3], e2[3];
+    uint32_t prim;    // original primitive id (tie-break + prim_to_shape index)
+};
+struct MeshDev {
+    const BvhNode*  nodes;
+    const TriDev*   tris;
+    const uint32_t* prim_to_shape;
+    const float*    shape_dissolve;
+    const float*    shape_diffuse;    // nshapes * 3 or nullptr
+    uint32_t        nnodes;
+};
+// Moeller-Trumbore with the operation order of the oracle's tri_hit (stand-in for rtcIntersect1,
+// Utils/EmbreeHelper.cpp:4-36; tnear = 0, tfar = inf)
+__device__ __forceinline__ bool tri_hit(const TriDev& tr, f3 org, f3 dir, float& t_out)
+{
+    float px = dir.y * tr.e2[2] - dir.z * tr.e2[1];
+    float py = dir.z * tr.e2[0] - dir.x * tr.e2[2];
+    float pz = dir.x * tr.e2[1] - dir.y * tr.e2[0];
+    float det = tr.e1[0] * px + tr.e1[1] * py + tr.e1[2] * pz;
+    if (det == 0.0f) return false;
+    float inv = 1.0f / det;
+    float tx = org.x - tr.v0[0], ty = org.y - tr.v0[1], tz = org.z - tr.v0[2];
+    float u = (tx * px + ty * py + tz * pz) * inv;
+    if (u < 0.0f || u > 1.0f) return false;
+    float qx = ty * tr.e1[2] - tz * tr.e1[1];
+    float qy = tz * tr.e1[0] - tx * tr.e1[2];
+    float qz = tx * tr.e1[1] - ty * tr.e1[0];
+    float v = (dir.x * qx + dir.y * qy + dir.z * qz) * inv;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = (tr.e2[0] * qx + tr.e2[1] * qy + tr.e2[2] * qz) * inv;
+    if (!(t >= 0.0f)) return false;
+    t_out = t;
+    return true;
+}
+
+// closest hit; returns primitive id or -1
+__device__ __forceinline__ int closest_hit(const MeshDev& m, f3 org, f3 dir, float& t_out)
+{
+    const float ix = 1.0f / dir.x, iy = 1.0f / dir.y, iz = 1.0f / dir.z;
+    float    best_t = __builtin_huge_valf();
+    uint32_t best_prim = 0xffffffffu;
+    uint32_t n = 0;
+    const BvhNode* nodes = m.nodes + ((dir.x < 0.0f ? 1u : 0u) | (dir.y < 0.0f ? 2u : 0u) | (dir.z < 0.0f ? 4u : 0u)) * m.nnodes;
+    while (n < m.nnodes) {
+        const BvhNode nd = nodes[n];
+        // slab test; fminf/fmaxf drop NaNs (0 * inf), which keeps the test conservative
+        float ax = (nd.lo[0] - org.x) * ix, bx = (nd.hi[0] - org.x) * ix;
+        float ay = (nd.lo[1] - org.y) * iy, by = (nd.hi[1] - org.y) * iy;
+        float az = (nd.lo[2] - org.z) * iz, bz = (nd.hi[2] - org.z) * iz;
+        float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+        float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_t));
+        if (tn <= tf) {
+            for (uint32_t k = 0; k < nd.count; ++k) {
+                const TriDev tr = m.tris[nd.first + k];
+                float        t;
+                if (tri_hit(tr, org, dir, t) && (t < best_t || (t == best_t && tr.prim < best_prim))) {
+                    best_t = t; best_prim = tr.prim;
+                }
+            }
+            n = n + 1;
+        } else {
+            n = nd.skip;
+        }
+    }
+    t_out = best_t;
+    return best_prim == 0xffffffffu ? -1 : (int)best_prim;
+}
+
+// Mesh-bounded media for the trackers (VR_INTEGRATOR_MESH_*_TRACKING) — NO REFERENCE COUNTERPART: the reference's
+// trackers clip to the grid bbox only (IntegratorDeltaTracking.cpp:37-39); SURVEY 8(d) config 5 defines the capability.
+// The medium interval of a ray is found by the walk the reference's MARCHERS do before they march
+// (IntegratorHomogeneousRayMarcherNEE.cpp:16-60, 104-108): closest hit; a hit on another object than the last one is
+// an entry and moves the origin to hit + dir * 0.001; the next hit on the same object is the exit.  A ray that starts
+// inside a medium (scattered rays, shadow rays) starts with that medium's object as "the last one".  Opaque shapes
+// (dissolve <= 0) are black absorbers.  [s0, s1] is in units of |dir| from org.  (oracle: mesh_segment)
+enum { SEG_NONE = 0, SEG_FOUND = 1, SEG_BLACK = 2 };
+__device__ __forceinline__ int mesh_segment(const MeshDev& m, f3 org, f3 dir, int inside_id, float& s0, float& s1, int& medium, uint32_t& n_queries)
+{
+    int   object = inside_id;
+    float s_acc = 0.0f, start = 0.0f;
+    for (int guard = 0; guard < 64; ++guard) {
+        float t;
+        n_queries++;
+        const int prim = closest_hit(m, org, dir, t);
+        if (prim < 0) return SEG_NONE;
+        const int previous = object;
+        object = (int)m.prim_to_shape[prim];
+        if (!(m.shape_dissolve[object] > 0)) return SEG_BLACK;
+        if (previous == object) { s0 = start; s1 = s_acc + t; medium = object; return SEG_FOUND; }
+        const f3 hit = add3(scale3(dir, t), org);
+        org = add3(hit, scale3(dir, 0.001f));
+        s_acc = (s_acc + t) + 0.001f;
+        start = s_acc;
+    }
+    return SEG_NONE;
+}
+// cut [t0, t1] by the mesh interval of the matching world-space ray; scale = index parameter per world parameter
+__device__ __forceinline__ int mesh_clip(const MeshDev& m, f3 worg, f3 wdir, float scale, int inside_id, int& medium, float& t0, float& t1,
+                                         bool& empty, uint32_t& n_queries)
+{
+    float s0 = 0.0f, s1 = 0.0f;
+    empty = false;
+    const int rc = mesh_segment(m, worg, wdir, inside_id, s0, s1, medium, n_queries);
+    if (rc != SEG_FOUND) return rc;
+    const float a = s0 * scale, b = s1 * scale;
+    if (a > t0) t0 = a;
+    if (b < t1) t1 = b;
+    if (t0 > t1) empty = true;
+    return rc;
+}
+// Map::applyMapF (NanoVDB.h:2249)
+__device__ __forceinline__ f3 index_to_world(const float* mat, const float* vec, f3 p)
+{
+    return mk3(fmaf(p.x, mat[0], fmaf(p.y, mat[1], fmaf(p.z, mat[2], vec[0]))), fmaf(p.x, mat[3], fmaf(p.y, mat[4], fmaf(p.z, mat[5], vec[1]))),
+               fmaf(p.x, mat[6], fmaf(p.y, mat[7], fmaf(p.z, mat[8], vec[2]))));
+}
+
+// Parameters only the event phases read (path set-up, scatter, shadow start/end).  They live in
+// device memory and are read with ordinary loads there, so that they do not occupy scalar
+// registers across the step loop.
+struct TrackCold {
+    CameraDev cam;
+    float     inv_mat[9], vec[3];
+    float     bmin[3], bmax1[3];     // float(bbox.min), float(bbox.max + 1)
+    float     g;
+    float     light[3], light_color[3];
+    float     emission[3], medium[3], background[3];
+    uint32_t  max_depth;
+    uint32_t  tile_h_log;           // work tiles are (64 >> tile_h_log) columns x (1 << tile_h_log) rows of the row set
+    GridDev   temperature;
+    // mesh-bounded trackers only (MESH kernels)
+    MeshDev   mesh;
+    float     mat[9];               // index -> world (Map::applyMapF), for the mesh queries of index-space rays
+};
+// Kernel argument: what the step loop reads.
+struct TrackParams {
+    const TrackCold* cold;
+    WorkDev   work;
+    GridDev   density;               // SKIP kernels: the skip grid (empty voxels hold -(empty-cube radius + 1))
+    int32_t   round_max, round_events; // step-loop trips per round / waiting lanes that end a round early
+    float     sigma_a, sigma_s, sigma_maj;
+    float     t_min, t_max, step_mult;
+    float     light_mult, shadow_mult;
+};
 
 // =============================================================================================
 // ratio / delta tracking
@@ -206,8 +339,11 @@ struct GeoVec<false> {
 // TEMP: a temperature grid is present (emission lookups); SPAN: steps are much shorter than a voxel,
 // remember the voxel's t-interval.  Compile-time too: as run-time flags in the step loop they cost
 // 2.5 % and 6.5 %.
-template <int INTEG, bool EXACT, bool SKIP, bool IS, bool TEMP, bool SPAN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VR_TRACK_WAVES(INTEG, EXACT, SPAN), VR_TRACK_WAVES(INTEG, EXACT, SPAN))))
+// MESH: the walks are cut to the mesh's entry/exit interval (mesh_segment; event phases only).  Those kernels keep one
+// more dword of lane state in LDS (the medium's object) and get a wave less per SIMD: closest_hit needs registers
+// while the step loop's state is alive.
+template <int INTEG, bool EXACT, bool SKIP, bool IS, bool TEMP, bool SPAN, bool MESH = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VR_TRACK_WAVES(INTEG, EXACT, SPAN) - (MESH && !(EXACT) ? 1 : 0), VR_TRACK_WAVES(INTEG, EXACT, SPAN) - (MESH && !(EXACT) ? 1 : 0))))
 vr_track_kernel(const TrackParams p)
 {
     typedef Math<EXACT> M;
@@ -224,7 +360,7 @@ vr_track_kernel(const TrackParams p)
     // ---- per-lane path state (HandleIntersectionData, BaseIntegrator.h:21-50) ----
     uint32_t st = ST_NEED;
     bool     shadow = false;            // walking directLightningRayMarch
-    __shared__ float s_cold[26][256];   // 26 KB per block: six blocks per CU fit the 160 KB of LDS
+    __shared__ float s_cold[MESH ? 27 : 26][256];   // 26 KB per block: six blocks per CU fit the 160 KB of LDS
     float* const cold_lane = &s_cold[0][threadIdx.x];
     uint32_t& item = *(uint32_t*)(cold_lane + 11 * 256);
     typedef GeoVec<VR_GEO_IN_LDS(INTEG, EXACT, SPAN)> Geo;
@@ -259,7 +395,8 @@ vr_track_kernel(const TrackParams p)
     // one density lookup per completed step of a walk: the walk's step index is added when the walk
     // ends (temperature lookups are counted where they happen)
     unsigned long long n_lookups = 0;
-    uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0;
+    uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0, n_queries = 0;
+    int&     medium = *(int*)(cold_lane + (MESH ? 26 : 11) * 256);   // MESH: object whose medium the walk is in (else unused alias)
     unsigned long long w_trips = 0, w_trip_lanes = 0, w_phases = 0;   // wave-uniform divergence counters
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's own range of work items
     bool     chunk_dry = false;               // every strip's counter has run past its last item
@@ -349,8 +486,16 @@ vr_track_kernel(const TrackParams p)
                 n_lookups += rng_step;
                 rng_ts |= 0x80000000u; rng_step = 0;
                 float c0 = 1e-5f, c1 = VR_FLT_MAX;
-                if (!ray_clip<EXACT>(so, light, c0, c1, c->bmin, c->bmax1)) {     // :229-232
-                    Tsh = 1.0f; st = ST_SHADOW_DONE;
+                int  seg = SEG_FOUND;
+                bool seg_empty = false;
+                const bool in_box = ray_clip<EXACT>(so, light, c0, c1, c->bmin, c->bmax1);
+                if (MESH && in_box) {
+                    int m2 = medium;
+                    seg = mesh_clip(c->mesh, index_to_world(c->mat, c->vec, so), mat_mult(c->mat, light), 1.0f, medium, m2, c0, c1, seg_empty, n_queries);
+                }
+                if (!in_box || (MESH && (seg == SEG_BLACK || seg_empty))) {       // :229-232
+                    Tsh = (MESH && in_box && seg == SEG_BLACK) ? 0.0f : 1.0f;     // an opaque surface between the point and the light
+                    st = ST_SHADOW_DONE;
                 } else {
                     shadow = true; Tsh = 1.0f; st = ST_WALK;
                     seed_stream();
@@ -397,7 +542,13 @@ vr_track_kernel(const TrackParams p)
                 wdir = scattered;                                                         // :178
                 shadow = false;
                 float c0 = 1e-5f, c1 = VR_FLT_MAX;
-                if (!ray_clip<EXACT>(scatter_p, scattered, c0, c1, c->bmin, c->bmax1)) {  // :182-187 "scattering failed"
+                int  seg = SEG_FOUND;
+                bool seg_empty = false;
+                const bool in_box = ray_clip<EXACT>(scatter_p, scattered, c0, c1, c->bmin, c->bmax1);
+                if (MESH && in_box)
+                    seg = mesh_clip(c->mesh, index_to_world(c->mat, c->vec, scatter_p), mat_mult(c->mat, scattered), 1.0f, medium, medium, c0, c1,
+                                    seg_empty, n_queries);
+                if (!in_box || (MESH && (seg == SEG_BLACK || seg_empty))) {               // :182-187 "scattering failed"
                     st = ST_FINISHED;
                 } else if (depth_remaining <= 0) {
                     // `while (... && depthRemaining > 0)`: out of scatter budget, the walk ends as
@@ -500,8 +651,17 @@ vr_track_kernel(const TrackParams p)
                     const float inv_length = M::rcp_(length);
                     const f3 ndir = mk3(inv_length * idir.x, inv_length * idir.y, inv_length * idir.z);
                     float c0 = length * 1e-5f, c1 = VR_FLT_MAX;
-                    if (!ray_clip<EXACT>(ieye, ndir, c0, c1, c->bmin, c->bmax1) || c->max_depth == 0) {
-                        // missed the grid (:37-39), or a zero scatter budget: the loop never runs (:55, :208)
+                    int  seg = SEG_FOUND;
+                    bool seg_empty = false;
+                    const bool in_box = ray_clip<EXACT>(ieye, ndir, c0, c1, c->bmin, c->bmax1);
+                    if (MESH && in_box) {
+                        medium = -1;
+                        seg = mesh_clip(c->mesh, weye, wdir, length, -1, medium, c0, c1, seg_empty, n_queries);
+                    }
+                    if (MESH && in_box && seg == SEG_BLACK) {
+                        store_sample(p.work.samples, item, mk3(0, 0, 0));                 // an opaque surface
+                    } else if (!in_box || c->max_depth == 0 || (MESH && (seg == SEG_NONE || seg_empty))) {
+                        // missed the grid (:37-39) or the mesh, or a zero scatter budget: the loop never runs (:55, :208)
                         store_sample(p.work.samples, item, mk3(c->background[0], c->background[1], c->background[2]));
                     } else {
                         st = ST_WALK; shadow = false;
@@ -683,7 +843,9 @@ vr_track_kernel(const TrackParams p)
     // ---- counters: one atomic per wave and counter ----
     unsigned long long a = wave_sum(n_paths), b = wave_sum(n_lookups), c = wave_sum(n_scatter), d = wave_sum(n_shadow),
                        e = wave_sum(n_limit);
+    const unsigned long long nq = MESH ? wave_sum(n_queries) : 0ull;
     if (lane == 0) {
+        if (MESH) atomicAdd(&p.work.counters->ray_queries, nq);
         atomicAdd(&p.work.counters->path_samples, a);
         atomicAdd(&p.work.counters->density_lookups, b);
         atomicAdd(&p.work.counters->scatter_events, c);
@@ -699,27 +861,6 @@ vr_track_kernel(const TrackParams p)
 // mesh-bounded fixed-step marchers
 // =============================================================================================
 
-// Threaded BVH in depth-first order: a node that is hit continues at node+1 (its first child, or
-// for a leaf the next subtree), a node that is missed continues at `skip`.  No stack.  MeshDev::nodes
-// holds eight such layouts of the same tree, one per sign octant of the ray direction, each visiting
-// the child nearer to its rays first.
-struct BvhNode {
-    float    lo[3], hi[3];
-    uint32_t skip;
-    uint32_t first, count;   // leaf: triangles [first, first+count); inner: count = 0
-};
-struct TriDev {
-    float    v0[3], e1[3], e2[3];
-    uint32_t prim;    // original primitive id (tie-break + prim_to_shape index)
-};
-struct MeshDev {
-    const BvhNode*  nodes;
-    const TriDev*   tris;
-    const uint32_t* prim_to_shape;
-    const float*    shape_dissolve;
-    const float*    shape_diffuse;    // nshapes * 3 or nullptr
-    uint32_t        nnodes;
-};
 struct MarchParams {
     CameraDev cam;
     WorkDev   work;
@@ -729,63 +870,6 @@ struct MarchParams {
     uint32_t  max_depth;
     uint32_t  tile_h_log;
 };
-
-// Moeller-Trumbore with the operation order of the oracle's tri_hit (stand-in for rtcIntersect1,
-// Utils/EmbreeHelper.cpp:4-36; tnear = 0, tfar = inf)
-__device__ __forceinline__ bool tri_hit(const TriDev& tr, f3 org, f3 dir, float& t_out)
-{
-    float px = dir.y * tr.e2[2] - dir.z * tr.e2[1];
-    float py = dir.z * tr.e2[0] - dir.x * tr.e2[2];
-    float pz = dir.x * tr.e2[1] - dir.y * tr.e2[0];
-    float det = tr.e1[0] * px + tr.e1[1] * py + tr.e1[2] * pz;
-    if (det == 0.0f) return false;
-    float inv = 1.0f / det;
-    float tx = org.x - tr.v0[0], ty = org.y - tr.v0[1], tz = org.z - tr.v0[2];
-    float u = (tx * px + ty * py + tz * pz) * inv;
-    if (u < 0.0f || u > 1.0f) return false;
-    float qx = ty * tr.e1[2] - tz * tr.e1[1];
-    float qy = tz * tr.e1[0] - tx * tr.e1[2];
-    float qz = tx * tr.e1[1] - ty * tr.e1[0];
-    float v = (dir.x * qx + dir.y * qy + dir.z * qz) * inv;
-    if (v < 0.0f || u + v > 1.0f) return false;
-    float t = (tr.e2[0] * qx + tr.e2[1] * qy + tr.e2[2] * qz) * inv;
-    if (!(t >= 0.0f)) return false;
-    t_out = t;
-    return true;
-}
-
-// closest hit; returns primitive id or -1
-__device__ __forceinline__ int closest_hit(const MeshDev& m, f3 org, f3 dir, float& t_out)
-{
-    const float ix = 1.0f / dir.x, iy = 1.0f / dir.y, iz = 1.0f / dir.z;
-    float    best_t = __builtin_huge_valf();
-    uint32_t best_prim = 0xffffffffu;
-    uint32_t n = 0;
-    const BvhNode* nodes = m.nodes + ((dir.x < 0.0f ? 1u : 0u) | (dir.y < 0.0f ? 2u : 0u) | (dir.z < 0.0f ? 4u : 0u)) * m.nnodes;
-    while (n < m.nnodes) {
-        const BvhNode nd = nodes[n];
-        // slab test; fminf/fmaxf drop NaNs (0 * inf), which keeps the test conservative
-        float ax = (nd.lo[0] - org.x) * ix, bx = (nd.hi[0] - org.x) * ix;
-        float ay = (nd.lo[1] - org.y) * iy, by = (nd.hi[1] - org.y) * iy;
-        float az = (nd.lo[2] - org.z) * iz, bz = (nd.hi[2] - org.z) * iz;
-        float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-        float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_t));
-        if (tn <= tf) {
-            for (uint32_t k = 0; k < nd.count; ++k) {
-                const TriDev tr = m.tris[nd.first + k];
-                float        t;
-                if (tri_hit(tr, org, dir, t) && (t < best_t || (t == best_t && tr.prim < best_prim))) {
-                    best_t = t; best_prim = tr.prim;
-                }
-            }
-            n = n + 1;
-        } else {
-            n = nd.skip;
-        }
-    }
-    t_out = best_t;
-    return best_prim == 0xffffffffu ? -1 : (int)best_prim;
-}
 
 // KIND: which handleIntersection marches the segment between entry and exit hit
 enum { MARCH_NEE = 0, MARCH_IMPROVED = 1, MARCH_PERLIN = 2, MARCH_DENSITY = 3 };

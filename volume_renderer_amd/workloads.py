@@ -89,7 +89,7 @@ def options_cloud(integrator, n, width, height, spp, regime="shipped", **kw):
     base = dict(width=width, height=height, widthReference=width, heightReference=height, rayPerPixelCount=spp,
                 maxDepth=16, cameraPosition=(0.0, 0.0, 2.2 * R), fov=45.0, lightPosition=(0.0, 1.0, 0.0),
                 lightColor=(1024.0, 1024.0, 1024.0), backgroundColor=BACKGROUND_SKY)
-    if integrator in ("ratioTracking", 2):
+    if integrator in ("ratioTracking", 2, "meshRatioTracking", 8):
         base.update(sigma_a=0.01, sigma_s=0.09, heyneyGreensteinG=0.924, stepSizeMin=0.005, stepSizeMax=9999.9,
                     stepSizeMultiplier=0.001)
     else:
@@ -105,6 +105,19 @@ def options_cloud(integrator, n, width, height, spp, regime="shipped", **kw):
 
 def cloud_radius(n):
     return 240.0 / 512.0 * n
+
+
+def options_mesh_tracker(integrator, n, width, height, spp, regime="shipped", **kw):
+    """BASELINE config 5, tracker leg: the cloud's step parameters (options_cloud) seen by the marchers' camera
+    (options_marcher); the n^3 grid is placed over the mesh with `mesh_tracker_grid_map`."""
+    base = dict(cameraPosition=(0.0, 0.825, 6.75), fov=60.0)
+    base.update(kw)
+    return options_cloud(integrator, n, width, height, spp, regime=regime, **base)
+
+
+def mesh_tracker_grid_map(n, extent=6.4, center=(0.0, 0.5, 0.0)):
+    """voxel_size and origin of an n^3 grid (bbox centred on index 0) that spans `extent` world units around `center`."""
+    return extent / n, tuple(float(c) for c in center)
 
 
 # ---- the reference's own committed renders (VolumeRenderer/Results/Oct_15_*.png) -------------------------------
