@@ -9,18 +9,23 @@ bunny-cloud-configRenderer.xml.  The density grid is generated on the device bef
 timed region, so inputs are resident in HBM when timing starts.
 
 Scaling over N GPUs (--scaling):
-  weak   (default) the frame keeps its resolution and every GPU keeps its sample count: the frame is rendered
-         at spp x N samples per pixel, rank r taking rows r::N — N GPUs buy N times the samples in the same
-         time.  At N = 1 this IS the named configuration.
-  strong the named frame itself (spp as configured) split by rows over the ranks; bounded by the fixed tail of
-         the longest paths.
+  strong (default) the NAMED frame itself (1080p at 64 spp for config 2) split by rows over the ranks, rank r
+         taking rows r::N; bounded by the fixed tail of the longest paths (DESIGN.md 7).  With N > 1 the line
+         carries an extra object "weak_scaling" measured right after the timed steps: the same frame at
+         spp x N samples per pixel (every GPU keeps its sample count).
+  weak   only the weak measurement, as the line's value.  At N = 1 both ARE the named configuration.
+The timed step ends with the gathered frame copied to host memory on rank 0 ("to gathered framebuffer
+on host").
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
   roofline      algorithmic density-lookup bytes (4 B per lookup, counted in-kernel) over the
-                HIP-event time of the integrator kernel, against the 8 TB/s HBM peak
+                HIP-event time of the integrator kernel, against the 8 TB/s HBM peak; inside it
+                "loads" = the same for the lookups that issued a load (4 B x voxel_loads: what the memory
+                system is asked for) and "valu" = wave-level VALU instructions per second against the issue
+                peak (1024 SIMDs x clock / 2) — what bounds the tracking kernels
   cpu_baseline  the CPU oracle (a port of the reference algorithm) on the host cores, on a
                 bounded sample of the same frame (N=1 only)
 """
@@ -38,6 +43,8 @@ import torch  # noqa: E402  (first: the backend shares torch's HIP runtime)
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_BYTES_PER_S = 8.0e12  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# MI355X_MICROARCH.md "Wave scheduling": 256 CUs x 4 SIMDs, a wave issues a VALU instruction over 2 cycles; 2.4 GHz
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
 BYTES_PER_LOOKUP = 4           # one f32 voxel per density lookup
 
 WORKLOADS = {
@@ -55,6 +62,11 @@ WORKLOADS = {
     "config5_marcher_sphere_4k": ("homogeneousRayMarcherImproved", "icosphere", 3840, 2160, 64, "mesh"),
     "config5_marcher_nee_sphere_4k": ("homogeneousRayMarcherNEE", "icosphere", 3840, 2160, 64, "mesh"),
     "perlin_marcher_sphere_1080p": ("heterogeneousPerlinNoise", "icosphere", 1920, 1080, 16, "mesh"),
+    # config 5, tracker leg: the trackers bounded by the mesh (no reference counterpart): the n^3 cloud laid
+    # over the 320-triangle sphere, seen by the marchers' camera
+    "config5_tracker_ratio_sphere_4k": ("meshRatioTracking", 1024, 3840, 2160, 16, "shipped"),
+    "config5_tracker_delta_sphere_4k": ("meshDeltaTracking", 1024, 3840, 2160, 256, "textbook"),
+    "config5_tracker_delta_shipped_sphere_4k": ("meshDeltaTracking", 1024, 3840, 2160, 64, "shipped"),
 }
 BVH_NODE_BYTES = 36            # one BvhNode per closest-hit query at the least (vr_kernels.h)
 
@@ -67,7 +79,7 @@ def parse():
     ap.add_argument("--workload", default="config2_ratio_1080p_64spp_cloud512", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="see the module docstring")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"], help="see the module docstring")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU work for the baseline sample")
     return ap.parse_args()
@@ -83,16 +95,24 @@ def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None):
     from volume_renderer_amd.abi import Grid, copy_options
     from volume_renderer_amd import workloads as scenes
 
-    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 64)
+    # every core this process may run on; the GPU box hands a one-GPU job a 16-core share of a much larger host
+    # (OMP_NUM_THREADS there, which worker pools must respect), so that is the honest "host cores" of the run
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = max(1, min(avail, share) if share > 0 else avail)
     L = ol.lib()
     L.vro_set_math_mode(ol.MATH_LIBM)
-    if mesh is not None:
+    if mesh is not None and not isinstance(n, int):
         scene, _keep = ol.make_scene(mesh=mesh)
     else:
         vox = np.zeros((n, n, n), dtype=np.float32)
         L.vro_make_cloud(n, scenes.cloud_radius(n), ol.fptr(vox), cores)
-        grid = Grid(vox)
-        scene, _keep = ol.make_scene(density=grid)
+        if mesh is not None:      # mesh-bounded trackers: the cloud laid over the mesh
+            vs, origin = scenes.mesh_tracker_grid_map(n)
+            grid = Grid(vox, voxel_size=vs, origin=origin)
+        else:
+            grid = Grid(vox)
+        scene, _keep = ol.make_scene(density=grid, mesh=mesh)
     o1 = copy_options(opts, rayPerPixelCount=1)   # 1 sub-sample per pixel, scaled linearly in spp
 
     def rows(row_list):
@@ -119,6 +139,7 @@ def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None):
         "value": samples / ts / 1e6,
         "unit": "Mpath-samples/s",
         "cores": cores,
+        "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"rows {stride // 2}::{stride} of the {W}x{H} frame ({len(sample)} rows), 1 of {opts.rayPerPixelCount} "
                   f"sub-samples per pixel, oracle/vr_oracle.c (libm, mt19937 per row) on {cores} threads, {ts:.1f} s",
@@ -147,44 +168,41 @@ def main():
 
     from volume_renderer_amd import MODE_EXACT, MODE_FAST, Backend, INTEGRATORS
     from volume_renderer_amd import workloads as scenes
+    from volume_renderer_amd.abi import copy_options
 
     integ, n, W, H, spp, regime = WORKLOADS[a.workload]
     if a.spp:
         spp = a.spp
-    spp_config = spp
-    if a.scaling == "weak":
-        spp *= world                                 # per-GPU sample count fixed: rows r::N at spp x N
     integ_id = INTEGRATORS[integ]
     mesh_scene = regime == "mesh"
+    mesh_tracker = integ.startswith("mesh")
 
     be = Backend(local)
     be.set_mode(MODE_EXACT if a.mode == "exact" else MODE_FAST)
     be.set_seed(scenes.SEED)
+    mesh = None
     if mesh_scene:
         opts = scenes.options_marcher(W, H, spp)
         mesh = scenes.cube_mesh() if n == "cube" else scenes.icosphere_mesh()
         be.set_mesh(mesh)                            # BVH resident in HBM before timing
     else:
-        opts = scenes.options_cloud(integ, n, W, H, spp, regime=regime)
-        if os.environ.get("VR_BENCH_CAMERA_DIST"):   # developer knob: camera distance in cloud radii (default 2.2)
-            opts.cameraPosition[2] = float(os.environ["VR_BENCH_CAMERA_DIST"]) * scenes.cloud_radius(n)
         be.generate_cloud(n, scenes.cloud_radius(n))     # density resident in HBM before timing
+        if mesh_tracker:
+            opts = scenes.options_mesh_tracker(integ, n, W, H, spp, regime=regime)
+            mesh = scenes.icosphere_mesh()
+            be.set_density_map(*scenes.mesh_tracker_grid_map(n))
+            be.set_mesh(mesh)
+        else:
+            opts = scenes.options_cloud(integ, n, W, H, spp, regime=regime)
+            if os.environ.get("VR_BENCH_CAMERA_DIST"):   # developer knob: camera distance in cloud radii (default 2.2)
+                opts.cameraPosition[2] = float(os.environ["VR_BENCH_CAMERA_DIST"]) * scenes.cloud_radius(n)
 
     from volume_renderer_amd.scheduler import RowScheduler
     sched = RowScheduler(H, W, torch.device("cpu") if rehearsal else dev, rank=rank, world=world)
     staging = torch.zeros_like(sched.part, device=dev) if rehearsal else None
-
-    def render_rows(first, stride, count, out):
-        target = staging if rehearsal else out
-        be.render_row_set_device(opts, integ_id, first, stride, count, target.data_ptr())
-        be.synchronize()
-        if rehearsal:
-            out.copy_(staging)
-
-    def step():
-        return sched.render(render_rows)
-
-    frame = sched.frame
+    # the frame's place in host memory (rank 0): the timed step ends there, as BaseIntegrator::render's span does
+    host_frame = torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True) if rank == 0 else None
+    cdev = torch.device("cpu") if rehearsal else dev
 
     def fence():
         torch.cuda.synchronize()
@@ -192,43 +210,102 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    kernel_ms = 0.0
-    launches = 0
-    lookups = 0
-    stats = None
-    for _ in range(a.steps):
-        step()
-        stats = be.last_stats()
-        kernel_ms += stats["kernel_ms"]
-        launches += stats["kernel_launches"]
-        lookups += stats["ray_queries"] if mesh_scene else stats["density_lookups"]
-    fence()
-    dt = time.perf_counter() - t0
-    cdev = torch.device("cpu") if rehearsal else dev
-    tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    agg = torch.tensor([float(lookups), float(kernel_ms), float(launches)], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-    dt = float(tt.item())
-    lookups_all, kernel_ms_all, launches_all = (float(x) for x in agg.tolist())
+    def run(o, steps, warmup):
+        """`warmup` untimed and `steps` timed frames of options `o`; max-over-ranks time and per-launch sums."""
+        def render_rows(first, stride, count, out):
+            target = staging if rehearsal else out
+            be.render_row_set_device(o, integ_id, first, stride, count, target.data_ptr())
+            be.synchronize()
+            if rehearsal:
+                out.copy_(staging)
 
+        def step():
+            frame = sched.render(render_rows)
+            if rank == 0:
+                host_frame.copy_(frame)              # device -> pinned host, synchronous
+            return frame
+
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        kernel_ms = 0.0
+        launches = 0
+        lookups = 0
+        loads = 0
+        stats = None
+        for _ in range(steps):
+            step()
+            stats = be.last_stats()
+            kernel_ms += stats["kernel_ms"]
+            launches += stats["kernel_launches"]
+            lookups += stats["ray_queries"] if mesh_scene else stats["density_lookups"]
+            loads += stats["voxel_loads"]
+        fence()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        agg = torch.tensor([float(lookups), float(kernel_ms), float(launches), float(loads)], dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        r = dict(zip(("lookups", "kernel_ms", "launches", "loads"), (float(x) for x in agg.tolist())))
+        r.update(dt=float(tt.item()), stats=stats, samples_per_step=W * H * o.rayPerPixelCount)
+        return r
+
+    weak = None
+    if a.scaling == "weak" and world > 1:
+        opts = copy_options(opts, rayPerPixelCount=spp * world)      # per-GPU sample count fixed: rows r::N at spp x N
+        main = run(opts, a.steps, a.warmup)
+        frame_mean = [float(x) for x in sched.frame.mean(dim=(0, 1)).tolist()] if rank == 0 else None
+    else:
+        main = run(opts, a.steps, a.warmup)                           # the named frame, split by rows
+        frame_mean = [float(x) for x in sched.frame.mean(dim=(0, 1)).tolist()] if rank == 0 else None
+        if world > 1:
+            w = run(copy_options(opts, rayPerPixelCount=spp * world), a.steps, 1)
+            weak = {"value": w["samples_per_step"] * a.steps / w["dt"] / 1e6, "unit": "Mpath-samples/s", "spp": spp * world,
+                    "ms_per_step": w["dt"] / a.steps * 1e3,
+                    "note": "same frame at spp x N samples per pixel, rows r::N per rank; measured after the timed steps"}
     if rank == 0:
-        samples_per_step = W * H * spp
+        dt, stats = main["dt"], main["stats"]
+        lookups_all, kernel_ms_all, launches_all, loads_all = main["lookups"], main["kernel_ms"], main["launches"], main["loads"]
+        samples_per_step = main["samples_per_step"]
         value = samples_per_step * a.steps / dt / 1e6
-        # dominant kernel = the tracking kernel; per-launch averages over every rank's launches
-        avg_launch_s = kernel_ms_all / 1e3 / max(launches_all, 1.0)
-        bytes_per_launch = lookups_all * (BVH_NODE_BYTES if mesh_scene else BYTES_PER_LOOKUP) / max(launches_all, 1.0)
-        achieved = bytes_per_launch / max(avg_launch_s, 1e-12) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                traffic = json.load(f).get(a.workload, {}).get("hbm_bytes_per_launch")
+        # dominant kernel = the integrator kernel; per-launch averages over every rank's launches
+        nl = max(launches_all, 1.0)
+        avg_launch_s = max(kernel_ms_all / 1e3 / nl, 1e-12)
+        bytes_per_launch = lookups_all * (BVH_NODE_BYTES if mesh_scene else BYTES_PER_LOOKUP) / nl
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f).get(a.workload, {})
+        use_pmc = world == 1 and not a.spp and a.mode == "fast"      # the committed counters are per launch of THIS frame
+        traffic = pmc.get("hbm_bytes_per_launch") if use_pmc else None
+        kernel_name = {0: "vr_march_kernel", 1: "vr_march_kernel", 6: "vr_march_kernel", 7: "vr_march_kernel", 4: "vr_gridmarch_kernel",
+                       5: "vr_gridmarch_kernel"}.get(integ_id, "vr_track_kernel")
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+            "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S, "traffic": traffic,
+            "kernel": kernel_name, "kernel_ms_per_launch": avg_launch_s * 1e3, "launches": int(launches_all),
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "note": ("algorithmic bytes = 36 B (one BVH node) x closest-hit queries: a lower bound, the BVH is L2-resident"
+                     if mesh_scene else
+                     "algorithmic bytes = 4 B x in-kernel lookup count (one per step, as the reference makes them); steps that stay "
+                     "in a voxel are served from a register and empty-space runs are taken arithmetically, so frac measures "
+                     "lookup rate; 'loads' is what the memory system is asked for, 'traffic' what HBM delivered (PMC, "
+                     "committed profile), 'valu' the bound the counters point to"),
+        }
+        if not mesh_scene:
+            loaded = loads_all * BYTES_PER_LOOKUP / nl
+            roofline["loads"] = {"bound": "hbm", "achieved": loaded / avg_launch_s / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+                                 "frac": loaded / avg_launch_s / HBM_PEAK_BYTES_PER_S, "bytes_per_launch": loaded,
+                                 "loads_per_lookup": loads_all / max(lookups_all, 1.0)}
+        if use_pmc and pmc.get("valu_insts_per_launch"):
+            rate = pmc["valu_insts_per_launch"] / avg_launch_s
+            roofline["valu"] = {"bound": "valu", "achieved": rate / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "unit": "G wave-instr/s",
+                                "frac": rate / VALU_PEAK_WAVE_INSTS_PER_S, "insts_per_launch": pmc["valu_insts_per_launch"],
+                                "source": pmc.get("valu_source")}
         out = {
             "metric": "Mpath-samples/sec at 1080p (1/2/4/8 GPU) + density lookups/s vs HBM roofline",
             "value": value,
@@ -238,38 +315,32 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": a.scaling,
+            "scaling": a.scaling if world > 1 else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": a.workload, "integrator": integ, "image": f"{W}x{H}", "spp": spp, "spp_at_1_gpu": spp_config,
+                "workload": a.workload, "integrator": integ, "image": f"{W}x{H}", "spp": int(opts.rayPerPixelCount), "spp_at_1_gpu": spp,
                 "grid": (f"{n} mesh, threaded BVH" if mesh_scene else
-                         f"{n}^3 procedural cloud (Perlin fbm), bricked 8^3, replicated per GPU"), "step_regime": regime,
+                         f"{n}^3 procedural cloud (Perlin fbm), bricked 8^3, replicated per GPU" +
+                         (", bounded by a 320-triangle sphere (threaded BVH)" if mesh_tracker else "")), "step_regime": regime,
                 "kernel_mode": a.mode,
                 "partition": ("REHEARSAL: all ranks on one GPU, gloo" if rehearsal else f"rows r::{world} per rank, RCCL all_gather") if world > 1 else "single GPU",
-                "frame_mean_rgb": [float(x) for x in frame.mean(dim=(0, 1)).tolist()],
+                "timed_span": "render + gather + frame copied to host memory on rank 0",
+                "frame_mean_rgb": frame_mean,
             },
             "glookups_per_s": lookups_all / max(kernel_ms_all / 1e3 / world, 1e-12) / 1e9,
             "lookups_per_sample": lookups_all / (samples_per_step * a.steps),
             "divergence": {k: stats[k] for k in ("wave_trips", "wave_trip_lanes", "event_phases", "scatter_events")}
             | {"walking_lanes_per_trip": stats["wave_trip_lanes"] / max(stats["wave_trips"], 1)},
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-                "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S, "traffic": traffic,
-                "kernel": {0: "vr_march_kernel", 1: "vr_march_kernel", 6: "vr_march_kernel", 4: "vr_gridmarch_kernel", 5: "vr_gridmarch_kernel"}.get(integ_id, "vr_track_kernel"),
-                "kernel_ms_per_launch": avg_launch_s * 1e3, "launches": int(launches_all),
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "note": ("algorithmic bytes = 36 B (one BVH node) x closest-hit queries: a lower bound, the BVH is L2-resident"
-                         if mesh_scene else
-                         "algorithmic bytes = 4 B x in-kernel lookup count; sub-voxel steps are served from a register, so "
-                         "frac measures lookup rate, not HBM traffic (see traffic)"),
-            },
+            "roofline": roofline,
         }
+        if weak is not None:
+            out["weak_scaling"] = weak
         want_cpu = a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and world == 1)
         if want_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(integ_id, n, opts, a.cpu_seconds, mesh if mesh_scene else None)
+                out["cpu_baseline"] = cpu_baseline(integ_id, n, opts, a.cpu_seconds, mesh)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mpath-samples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)

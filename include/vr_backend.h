@@ -62,6 +62,11 @@ int vr_backend_set_density(vr_backend* b, const vr_grid_desc* density, const vr_
  * (its fields come from .nvdb files that are absent from the checkout). */
 int vr_backend_generate_cloud(vr_backend* b, int n, float radius_voxels);
 
+/* Replaces the Map of the grid that is resident (world = voxel_size * index + origin): places the
+ * generated cloud over a mesh for the mesh-bounded trackers.  The reference reads the Map from the
+ * .nvdb file (grid->map(), used through worldToIndexF, nanovdb/util/Ray.h:257-267). */
+int vr_backend_set_density_map(vr_backend* b, float voxel_size, const float origin_xyz[3]);
+
 /* Reads the bricked density back as a dense k-fastest array of dims[0]*dims[1]*dims[2]
  * floats (for checks); dims/bbox_min may be NULL. */
 int vr_backend_read_density(vr_backend* b, float* voxels, uint64_t capacity_floats, int32_t dims[3], int32_t bbox_min[3]);
@@ -144,6 +149,41 @@ int vr_backend_max_channel_device(vr_backend* b, const void* d_rgb, uint64_t npi
  * [0,1], *255 truncated; out = top-down RGB8 (the reference's flip puts framebuffer row 0 at
  * the top of the PNG).  Host buffers. */
 int vr_rgb_to_u8(const float* rgb, uint32_t width, uint32_t height, uint8_t* out_rgb8);
+
+/* ---- one frame over several GPUs ---------------------------------------------------------
+ * Replaces the fan-out INSIDE BaseIntegrator::render (BaseIntegrator.cpp:143-181: N worker threads
+ * drawing row chunks from Utils/MultithreadingHelper.cpp:10-28, joined before the timed span ends at
+ * :192): a vr_backend_group holds one vr_backend (own stream, own copy of the scene) per listed GPU
+ * and is driven from ONE host thread in ONE process.  vr_group_render gives device i of N the rows
+ * i, i+N, i+2N, ... of the frame, launches all devices before it waits for any, and gathers the row
+ * blocks into the caller's HOST framebuffer (each device copies its rows straight to their interleaved
+ * places, so the frame is bit-identical for every N: the random streams are keyed by absolute pixel
+ * and sample).  vr_group_render_device gathers into DEVICE memory of the group's first GPU instead
+ * (peer copies over xGMI; the frame can then be tonemapped there with vr_backend_tonemap_device on
+ * vr_group_backend(g, 0)).  A device ordinal may be listed more than once (a rehearsal of N > 1 on a
+ * box with one GPU; never a measurement).  The multi-process way — one rank per GPU, RCCL
+ * all_gather — is volume_renderer_amd/scheduler.py over the same row sets. */
+typedef struct vr_backend_group vr_backend_group;
+int  vr_group_create(const int* hip_device_ordinals, uint32_t ndevices, vr_backend_group** out);
+void vr_group_destroy(vr_backend_group* g);
+uint32_t    vr_group_size(const vr_backend_group* g);
+vr_backend* vr_group_backend(vr_backend_group* g, uint32_t index);   /* borrowed; NULL when out of range */
+const char* vr_group_last_error(const vr_backend_group* g);          /* g may be NULL: last failing vr_group_create */
+/* the scene and the knobs, replicated on every device of the group (288 GB of HBM each) */
+int vr_group_set_density(vr_backend_group* g, const vr_grid_desc* density, const vr_grid_desc* temperature);
+int vr_group_generate_cloud(vr_backend_group* g, int n, float radius_voxels);
+int vr_group_set_density_map(vr_backend_group* g, float voxel_size, const float origin_xyz[3]);
+int vr_group_set_mesh(vr_backend_group* g, const vr_mesh_desc* mesh);
+int vr_group_set_mode(vr_backend_group* g, int vr_mode);
+int vr_group_set_seed(vr_backend_group* g, uint64_t philox_key);
+/* BaseIntegrator::render up to :192 over all devices of the group; framebuffer_rgb = width*height*3
+ * floats of HOST memory.  Returns after every device's rows have arrived. */
+int vr_group_render(vr_backend_group* g, const vr_options_pod* o, int integrator, float* framebuffer_rgb);
+/* The same with the frame gathered in HBM: d_rgb = width*height*3 floats on the group's first GPU. */
+int vr_group_render_device(vr_backend_group* g, const vr_options_pod* o, int integrator, void* d_rgb);
+/* Counters summed over the devices; kernel_ms = the slowest device's integrator kernel time (the
+ * devices run side by side), kernel_launches = the sum. */
+int vr_group_last_stats(vr_backend_group* g, vr_render_stats* stats, float* kernel_ms, uint32_t* kernel_launches);
 
 /* sizeof() of the boundary structs as compiled, for binding self-checks */
 void vr_abi_sizes(uint32_t out[4]); /* options, grid_desc, mesh_desc, render_stats */

@@ -124,6 +124,10 @@ typedef struct vr_render_stats {
     uint64_t wave_trips;       /* trips of a wave through the step loop */
     uint64_t wave_trip_lanes;  /* lanes that were walking, summed over those trips (<= 64 per trip) */
     uint64_t event_phases;     /* event phases run by a wave (scatter / shadow end / refill) */
+    /* density_lookups that issued a load on the GPU; the others found the voxel of the previous step
+     * in the lane's register (sub-voxel steps) or were taken arithmetically as an empty-space run.
+     * 4 B x voxel_loads is what the memory system is asked for.  0 from the CPU oracle. */
+    uint64_t voxel_loads;
 } vr_render_stats;
 
 /* Error codes returned by every vr_* entry point (0 = success).  The reference has no

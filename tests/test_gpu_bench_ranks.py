@@ -29,8 +29,11 @@ def run_bench(nranks, *args):
 
 def test_two_ranks_weak_and_strong():
     one = run_bench(1, "--spp", "8")
-    weak = run_bench(2)                                # small is 4 spp: two ranks render 8
-    strong = run_bench(2, "--scaling", "strong", "--spp", "8")
+    weak = run_bench(2, "--scaling", "weak")           # small is 4 spp: two ranks render 8
+    strong = run_bench(2, "--spp", "8")                # the default: the named frame split by rows, weak measured beside it
+    assert strong["weak_scaling"]["spp"] == 16 and strong["weak_scaling"]["value"] > 0 and "weak_scaling" not in one
+    assert one["scaling"] == "strong" and one["config"]["timed_span"].endswith("host memory on rank 0")
+    assert one["roofline"]["loads"]["bytes_per_launch"] <= one["roofline"]["algorithmic_bytes_per_launch"]
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["spp"] == 8 and weak["config"]["spp_at_1_gpu"] == 4
     assert strong["scaling"] == "strong" and strong["config"]["spp"] == 8
     # the frame does not depend on how many ranks rendered it (streams keyed by absolute pixel and sample)

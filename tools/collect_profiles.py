@@ -58,6 +58,10 @@ json.dump(out, open(os.path.join(P, f"{tag}_bench_pmc_track_kernel.json"), "w"),
 tpath = os.path.join(P, "pmc_traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 traffic[workload] = {"hbm_bytes_per_launch": hbm, "source": f"profiles/{tag}_bench_pmc_track_kernel.json"}
+if "prof_sq" in out and "SQ_INSTS_VALU" in out["prof_sq"]["counters_sum_over_launches"]:
+    sq = out["prof_sq"]
+    traffic[workload]["valu_insts_per_launch"] = sq["counters_sum_over_launches"]["SQ_INSTS_VALU"] / sq["launches"]
+    traffic[workload]["valu_source"] = f"SQ_INSTS_VALU, profiles/{tag}_bench_pmc_track_kernel.json"
 json.dump(traffic, open(tpath, "w"), indent=1)
 print(open(os.path.join(P, f"{tag}_bench_kernel_stats.csv")).read()[:600])
 print(json.dumps(out["derived"], indent=1))

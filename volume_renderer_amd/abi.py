@@ -112,6 +112,7 @@ class RenderStats(C.Structure):
         ("wave_trips", C.c_uint64),
         ("wave_trip_lanes", C.c_uint64),
         ("event_phases", C.c_uint64),
+        ("voxel_loads", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -25,7 +25,10 @@ EXPORTS = [
     "vr_backend_set_mode", "vr_backend_set_seed", "vr_backend_set_sample_buffer_bytes", "vr_backend_render_rows",
     "vr_backend_render", "vr_backend_render_row_set_device", "vr_backend_synchronize", "vr_backend_last_stats",
     "vr_backend_tonemap_device", "vr_backend_max_channel_device", "vr_rgb_to_u8", "vr_abi_sizes",
-    "vr_backend_render_row_set_device_noalloc",
+    "vr_backend_render_row_set_device_noalloc", "vr_backend_set_density_map",
+    "vr_group_create", "vr_group_destroy", "vr_group_size", "vr_group_backend", "vr_group_last_error", "vr_group_set_density",
+    "vr_group_generate_cloud", "vr_group_set_density_map", "vr_group_set_mesh", "vr_group_set_mode", "vr_group_set_seed",
+    "vr_group_render", "vr_group_render_device", "vr_group_last_stats",
 ]
 
 
@@ -78,6 +81,25 @@ def lib():
     L.vr_backend_generate_cloud.argtypes = [vp, C.c_int, C.c_float]
     L.vr_backend_read_density.argtypes = [vp, C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.vr_backend_density_max.argtypes = [vp, C.POINTER(C.c_float)]
+    L.vr_backend_set_density_map.argtypes = [vp, C.c_float, C.POINTER(C.c_float)]
+    L.vr_group_create.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]
+    L.vr_group_destroy.argtypes = [vp]
+    L.vr_group_destroy.restype = None
+    L.vr_group_size.argtypes = [vp]
+    L.vr_group_size.restype = C.c_uint32
+    L.vr_group_backend.argtypes = [vp, C.c_uint32]
+    L.vr_group_backend.restype = vp
+    L.vr_group_last_error.argtypes = [vp]
+    L.vr_group_last_error.restype = C.c_char_p
+    L.vr_group_set_density.argtypes = [vp, C.POINTER(GridDesc), C.POINTER(GridDesc)]
+    L.vr_group_generate_cloud.argtypes = [vp, C.c_int, C.c_float]
+    L.vr_group_set_density_map.argtypes = [vp, C.c_float, C.POINTER(C.c_float)]
+    L.vr_group_set_mesh.argtypes = [vp, C.POINTER(MeshDesc)]
+    L.vr_group_set_mode.argtypes = [vp, C.c_int]
+    L.vr_group_set_seed.argtypes = [vp, C.c_uint64]
+    L.vr_group_render.argtypes = [vp, C.POINTER(OptionsPod), C.c_int, C.POINTER(C.c_float)]
+    L.vr_group_render_device.argtypes = [vp, C.POINTER(OptionsPod), C.c_int, vp]
+    L.vr_group_last_stats.argtypes = [vp, C.POINTER(RenderStats), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.vr_backend_set_mesh.argtypes = [vp, C.POINTER(MeshDesc)]
     L.vr_backend_set_mode.argtypes = [vp, C.c_int]
     L.vr_backend_set_seed.argtypes = [vp, C.c_uint64]
@@ -157,6 +179,9 @@ class Backend:
     def generate_cloud(self, n, radius_voxels):
         self._check(self._L.vr_backend_generate_cloud(self._h, int(n), float(radius_voxels)))
 
+    def set_density_map(self, voxel_size, origin):
+        self._check(self._L.vr_backend_set_density_map(self._h, float(voxel_size), (C.c_float * 3)(*[float(x) for x in origin])))
+
     def read_density(self):
         dims = (C.c_int32 * 3)()
         bmin = (C.c_int32 * 3)()
@@ -235,6 +260,93 @@ class Backend:
         out = C.c_float()
         self._check(self._L.vr_backend_max_channel_device(self._h, C.c_void_p(int(device_ptr)), int(npixels), C.byref(out)))
         return out.value
+
+
+class BackendGroup:
+    """One frame over several GPUs in one process (vr_backend_group*): device i of N renders rows i::N.
+
+    `devices` may name a GPU more than once (a rehearsal of N > 1 on a one-GPU box)."""
+
+    def __init__(self, devices):
+        self._L = lib()
+        devs = [int(d) for d in devices]
+        h = C.c_void_p()
+        rc = self._L.vr_group_create((C.c_int * len(devs))(*devs), len(devs), C.byref(h))
+        if rc != 0:
+            raise BackendError(rc, self._L.vr_group_last_error(None).decode())
+        self._h = h
+        self.devices = devs
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vr_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __len__(self):
+        return int(self._L.vr_group_size(self._h))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BackendError(rc, self._L.vr_group_last_error(self._h).decode())
+
+    def set_density(self, density, temperature=None):
+        t = C.byref(temperature.desc) if temperature is not None else None
+        self._check(self._L.vr_group_set_density(self._h, C.byref(density.desc), t))
+
+    def generate_cloud(self, n, radius_voxels):
+        self._check(self._L.vr_group_generate_cloud(self._h, int(n), float(radius_voxels)))
+
+    def set_density_map(self, voxel_size, origin):
+        self._check(self._L.vr_group_set_density_map(self._h, float(voxel_size), (C.c_float * 3)(*[float(x) for x in origin])))
+
+    def set_mesh(self, mesh):
+        self._check(self._L.vr_group_set_mesh(self._h, C.byref(mesh.desc)))
+
+    def set_mode(self, mode):
+        self._check(self._L.vr_group_set_mode(self._h, int(mode)))
+
+    def set_seed(self, seed):
+        self._check(self._L.vr_group_set_seed(self._h, int(seed)))
+
+    def render(self, opts, integrator):
+        """BaseIntegrator::render minus tonemap/save over all devices -> float32 (height, width, 3) on the host."""
+        fb = np.zeros((opts.height, opts.width, 3), dtype=np.float32)
+        self._check(self._L.vr_group_render(self._h, C.byref(opts), integrator_id(integrator), fb.ctypes.data_as(C.POINTER(C.c_float))))
+        return fb
+
+    def render_device(self, opts, integrator, device_ptr):
+        """The same with the frame gathered at device_ptr (height*width*3 floats) on the group's first GPU."""
+        self._check(self._L.vr_group_render_device(self._h, C.byref(opts), integrator_id(integrator), C.c_void_p(int(device_ptr))))
+
+    def tonemap_device(self, device_ptr, npixels, max_white=-1.0):
+        out = C.c_float()
+        b0 = self._L.vr_group_backend(self._h, 0)
+        rc = self._L.vr_backend_tonemap_device(b0, C.c_void_p(int(device_ptr)), int(npixels), float(max_white), C.byref(out))
+        if rc != 0:
+            raise BackendError(rc, self._L.vr_backend_last_error(b0).decode())
+        return out.value
+
+    def last_stats(self):
+        st = RenderStats()
+        ms = C.c_float()
+        n = C.c_uint32()
+        self._check(self._L.vr_group_last_stats(self._h, C.byref(st), C.byref(ms), C.byref(n)))
+        d = st.as_dict()
+        d["kernel_ms"] = ms.value
+        d["kernel_launches"] = n.value
+        return d
 
 
 def rgb_to_u8(rgb):

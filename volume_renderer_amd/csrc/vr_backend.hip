@@ -863,6 +863,7 @@ int collect(vr_backend* b)
     b->stats.scatter_events = c.scatter_events; b->stats.shadow_rays = c.shadow_rays;
     b->stats.ray_queries = c.ray_queries; b->stats.step_limit_hits = c.step_limit_hits;
     b->stats.wave_trips = c.wave_trips; b->stats.wave_trip_lanes = c.wave_trip_lanes; b->stats.event_phases = c.event_phases;
+    b->stats.voxel_loads = c.voxel_loads;
     if (c.step_limit_hits) return fail(b, VR_ERR_STEP_LIMIT, "%llu paths hit the per-path step cap", (unsigned long long)c.step_limit_hits);
     return VR_OK;
 }
@@ -995,6 +996,17 @@ int vr_backend_generate_cloud(vr_backend* b, int n, float radius_voxels)
     rc = build_derived(b);
     if (rc) return rc;
     b->has_density = true;
+    return VR_OK;
+}
+
+int vr_backend_set_density_map(vr_backend* b, float voxel_size, const float origin_xyz[3])
+{
+    if (!b) return VR_ERR_INVALID_ARG;
+    if (!b->has_density) return fail(b, VR_ERR_NO_DENSITY, "no density grid");
+    if (!(voxel_size > 0.0f) || !origin_xyz) return fail(b, VR_ERR_INVALID_ARG, "voxel_size must be > 0 and origin not NULL");
+    const float inv = 1.0f / voxel_size;
+    for (int i = 0; i < 9; ++i) { b->mat[i] = (i % 4 == 0) ? voxel_size : 0.0f; b->inv_mat[i] = (i % 4 == 0) ? inv : 0.0f; }
+    for (int i = 0; i < 3; ++i) b->vec[i] = origin_xyz[i];
     return VR_OK;
 }
 
@@ -1186,6 +1198,171 @@ int vr_backend_tonemap_device(vr_backend* b, void* d_rgb, uint64_t npixels, floa
         HIP_TRY(b, hipGetLastError());
     }
     HIP_TRY(b, hipStreamSynchronize(b->stream));
+    return VR_OK;
+}
+
+// ---- one frame over several GPUs (BaseIntegrator.cpp:143-181) ----------------------------------
+} // extern "C"
+
+struct vr_backend_group {
+    std::vector<vr_backend*> dev;
+    std::string              err;
+    bool                     rendered = false;
+};
+
+namespace {
+thread_local std::string g_group_create_error;
+
+int group_fail(vr_backend_group* g, int code, uint32_t index, const vr_backend* b)
+{
+    char head[64];
+    snprintf(head, sizeof head, "device %u of the group (GPU %d): ", index, b ? b->device : -1);
+    g->err = std::string(head) + (b ? b->err : std::string("no backend"));
+    return code;
+}
+#define VR_GROUP_EACH(g, call)                                             \
+    do {                                                                   \
+        if (!(g)) return VR_ERR_INVALID_ARG;                               \
+        for (uint32_t i_ = 0; i_ < (g)->dev.size(); ++i_) {                \
+            vr_backend* b = (g)->dev[i_];                                  \
+            const int   rc_ = (call);                                      \
+            if (rc_) return group_fail((g), rc_, i_, b);                   \
+        }                                                                  \
+        return VR_OK;                                                      \
+    } while (0)
+
+// rows i, i+N, ... of the frame on device i, all devices launched before any is waited for; each device then copies
+// its row block to the rows' places in the frame (host memory, or memory of the group's first GPU)
+int group_render(vr_backend_group* g, const vr_options_pod* o, int integrator, float* frame, bool frame_on_device)
+{
+    if (!g) return VR_ERR_INVALID_ARG;
+    if (!o || !frame) { g->err = "options or framebuffer == NULL"; return VR_ERR_INVALID_ARG; }
+    const uint32_t N = (uint32_t)g->dev.size(), H = o->height, W = o->width;
+    std::vector<uint32_t> count(N, 0);
+    for (uint32_t i = 0; i < N; ++i) {
+        vr_backend* b = g->dev[i];
+        count[i] = i < H ? (H - i + N - 1) / N : 0;
+        int rc = use_device(b);
+        if (!rc && count[i]) rc = ensure(b, b->d_rows, b->rows_cap, (size_t)count[i] * W * 3);
+        if (rc) return group_fail(g, rc, i, b);
+    }
+    for (uint32_t i = 0; i < N; ++i) {
+        vr_backend* b = g->dev[i];
+        b->stats = vr_render_stats{}; b->passes_used = 0; b->launches = 0; b->last_counters = nullptr;
+        if (!count[i]) {
+            const int rc = validate(b, o, integrator);      // a device without rows still reports a bad call
+            if (rc) return group_fail(g, rc, i, b);
+            continue;
+        }
+        const int rc = render_row_set(b, o, integrator, i, N, count[i], b->d_rows, false);
+        if (rc) return group_fail(g, rc, i, b);
+    }
+    const size_t row_bytes = (size_t)W * 3 * sizeof(float);
+    for (uint32_t i = 0; i < N; ++i) {
+        vr_backend* b = g->dev[i];
+        if (!count[i]) continue;
+        int rc = use_device(b);
+        if (rc) return group_fail(g, rc, i, b);
+        const hipError_t e = hipMemcpy2DAsync((char*)frame + (size_t)i * row_bytes, (size_t)N * row_bytes, b->d_rows, row_bytes, row_bytes,
+                                              count[i], frame_on_device ? hipMemcpyDefault : hipMemcpyDeviceToHost, b->stream);
+        if (e != hipSuccess) {
+            fail(b, VR_ERR_HIP, "gather of the row block: %s", hipGetErrorString(e));
+            return group_fail(g, VR_ERR_HIP, i, b);
+        }
+    }
+    int first_rc = VR_OK;
+    for (uint32_t i = 0; i < N; ++i) {          // wait for every device even when one failed
+        vr_backend* b = g->dev[i];
+        int rc = use_device(b);
+        if (!rc) rc = count[i] ? collect(b) : VR_OK;
+        if (rc && !first_rc) first_rc = group_fail(g, rc, i, b);
+    }
+    g->rendered = first_rc == VR_OK;
+    return first_rc;
+}
+} // namespace
+
+extern "C" {
+
+int vr_group_create(const int* ordinals, uint32_t ndevices, vr_backend_group** out)
+{
+    if (!out) { g_group_create_error = "out == NULL"; return VR_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (!ordinals || ndevices == 0 || ndevices > 64) { g_group_create_error = "device list empty, NULL or longer than 64"; return VR_ERR_INVALID_ARG; }
+    vr_backend_group* g = new vr_backend_group;
+    for (uint32_t i = 0; i < ndevices; ++i) {
+        vr_backend* b = nullptr;
+        const int   rc = vr_backend_create(ordinals[i], &b);
+        if (rc) {
+            g_group_create_error = "device " + std::to_string(i) + " of the list: " + vr_backend_last_error(nullptr);
+            vr_group_destroy(g);
+            return rc;
+        }
+        g->dev.push_back(b);
+    }
+    // the first GPU's memory is the target of vr_group_render_device's gather: let the others write to it
+    for (uint32_t i = 1; i < ndevices; ++i) {
+        if (g->dev[i]->device == g->dev[0]->device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, g->dev[i]->device, g->dev[0]->device) == hipSuccess && can) {
+            (void)hipSetDevice(g->dev[i]->device);
+            const hipError_t e = hipDeviceEnablePeerAccess(g->dev[0]->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // the copy then goes through the host
+            else (void)hipGetLastError();
+        }
+    }
+    *out = g;
+    return VR_OK;
+}
+
+void vr_group_destroy(vr_backend_group* g)
+{
+    if (!g) return;
+    for (vr_backend* b : g->dev) vr_backend_destroy(b);
+    delete g;
+}
+
+uint32_t    vr_group_size(const vr_backend_group* g) { return g ? (uint32_t)g->dev.size() : 0u; }
+vr_backend* vr_group_backend(vr_backend_group* g, uint32_t index) { return g && index < g->dev.size() ? g->dev[index] : nullptr; }
+const char* vr_group_last_error(const vr_backend_group* g) { return g ? g->err.c_str() : g_group_create_error.c_str(); }
+
+int vr_group_set_density(vr_backend_group* g, const vr_grid_desc* density, const vr_grid_desc* temperature) { VR_GROUP_EACH(g, vr_backend_set_density(b, density, temperature)); }
+int vr_group_generate_cloud(vr_backend_group* g, int n, float radius_voxels) { VR_GROUP_EACH(g, vr_backend_generate_cloud(b, n, radius_voxels)); }
+int vr_group_set_density_map(vr_backend_group* g, float voxel_size, const float origin_xyz[3]) { VR_GROUP_EACH(g, vr_backend_set_density_map(b, voxel_size, origin_xyz)); }
+int vr_group_set_mesh(vr_backend_group* g, const vr_mesh_desc* mesh) { VR_GROUP_EACH(g, vr_backend_set_mesh(b, mesh)); }
+int vr_group_set_mode(vr_backend_group* g, int mode) { VR_GROUP_EACH(g, vr_backend_set_mode(b, mode)); }
+int vr_group_set_seed(vr_backend_group* g, uint64_t seed) { VR_GROUP_EACH(g, vr_backend_set_seed(b, seed)); }
+
+int vr_group_render(vr_backend_group* g, const vr_options_pod* o, int integrator, float* framebuffer_rgb)
+{
+    return group_render(g, o, integrator, framebuffer_rgb, false);
+}
+int vr_group_render_device(vr_backend_group* g, const vr_options_pod* o, int integrator, void* d_rgb)
+{
+    return group_render(g, o, integrator, (float*)d_rgb, true);
+}
+
+int vr_group_last_stats(vr_backend_group* g, vr_render_stats* stats, float* kernel_ms, uint32_t* kernel_launches)
+{
+    if (!g) return VR_ERR_INVALID_ARG;
+    vr_render_stats sum{};
+    float           slowest = 0.0f;
+    uint32_t        launches = 0;
+    for (uint32_t i = 0; i < g->dev.size(); ++i) {
+        vr_render_stats st{};
+        float           ms = 0.0f;
+        uint32_t        n = 0;
+        const int rc = vr_backend_last_stats(g->dev[i], &st, &ms, &n);
+        if (rc) return group_fail(g, rc, i, g->dev[i]);
+        uint64_t*       a = (uint64_t*)&sum;
+        const uint64_t* c = (const uint64_t*)&st;
+        for (size_t k = 0; k < sizeof(vr_render_stats) / sizeof(uint64_t); ++k) a[k] += c[k];
+        slowest = std::max(slowest, ms);
+        launches += n;
+    }
+    if (stats) *stats = sum;
+    if (kernel_ms) *kernel_ms = slowest;
+    if (kernel_launches) *kernel_launches = launches;
     return VR_OK;
 }
 

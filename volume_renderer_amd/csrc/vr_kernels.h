@@ -31,6 +31,7 @@ enum { INTEG_RATIO = 2, INTEG_DELTA = 3 };
 struct Counters {
     unsigned long long path_samples, density_lookups, scatter_events, shadow_rays, ray_queries, step_limit_hits;
     unsigned long long wave_trips, wave_trip_lanes, event_phases;
+    unsigned long long voxel_loads;   // lookups that issued a load (the rest were served from the lane's register)
 };
 
 // Camera block: renderPartial's per-chunk constants + renderRay's per-pixel arithmetic
@@ -286,6 +287,12 @@ enum {
 #ifndef VR_TRIP_ITERS_PLAIN
 #define VR_TRIP_ITERS_PLAIN 1
 #endif
+// per-lane count of the voxel loads issued (vr_render_stats::voxel_loads); -DVR_NO_LOAD_COUNT builds measure its cost
+#ifdef VR_NO_LOAD_COUNT
+#define VR_COUNT_LOAD(n) ((void)0)
+#else
+#define VR_COUNT_LOAD(n) ((n)++)
+#endif
 // work hand-out of the tracking kernel: vertical strips of tile columns, one per XCD
 #define VR_TRACK_STRIPS 8
 
@@ -398,6 +405,7 @@ vr_track_kernel(const TrackParams p)
     uint32_t n_paths = 0, n_scatter = 0, n_shadow = 0, n_limit = 0, n_queries = 0;
     int&     medium = *(int*)(cold_lane + (MESH ? 26 : 11) * 256);   // MESH: object whose medium the walk is in (else unused alias)
     unsigned long long w_trips = 0, w_trip_lanes = 0, w_phases = 0;   // wave-uniform divergence counters
+    uint32_t n_loads = 0;                     // voxel loads this lane issued (the other lookups found the voxel in its register)
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's own range of work items
     bool     chunk_dry = false;               // every strip's counter has run past its last item
     uint32_t strip_try = 0, strip_lo = 0, strip_w = 0;   // wave-uniform: the strip of tile columns the chunk came from
@@ -417,7 +425,7 @@ vr_track_kernel(const TrackParams p)
         if (in) {
             n_off = brick_offset(p.density, (uint32_t)i, (uint32_t)j, (uint32_t)k);
             n_val = cur_val;
-            if (n_off != cur_off) n_val = p.density.bricks[n_off];
+            if (n_off != cur_off) { n_val = p.density.bricks[n_off]; VR_COUNT_LOAD(n_loads); }
             if (SPAN || SKIP)
                 // ray parameter at which the walk leaves the voxel shrunk by `slack` on every side (see empty_run)
             {
@@ -785,6 +793,7 @@ vr_track_kernel(const TrackParams p)
                         const TrackCold* c = opaque(p.cold);
                         const float emission = grid_value_nocache(c->temperature, ray_at(eye, dir, t));
                         n_lookups++;
+                        n_loads++;
                         if (emission > 0.0f) {
                             f3 e = scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), T * (sigma * p.sigma_a));
                             e = scale3(e, emission);
@@ -844,6 +853,7 @@ vr_track_kernel(const TrackParams p)
     unsigned long long a = wave_sum(n_paths), b = wave_sum(n_lookups), c = wave_sum(n_scatter), d = wave_sum(n_shadow),
                        e = wave_sum(n_limit);
     const unsigned long long nq = MESH ? wave_sum(n_queries) : 0ull;
+    const unsigned long long nl = wave_sum(n_loads);
     if (lane == 0) {
         if (MESH) atomicAdd(&p.work.counters->ray_queries, nq);
         atomicAdd(&p.work.counters->path_samples, a);
@@ -854,6 +864,7 @@ vr_track_kernel(const TrackParams p)
         atomicAdd(&p.work.counters->wave_trips, w_trips);
         atomicAdd(&p.work.counters->wave_trip_lanes, w_trip_lanes);
         atomicAdd(&p.work.counters->event_phases, w_phases);
+        atomicAdd(&p.work.counters->voxel_loads, nl);
     }
 }
 
@@ -1224,6 +1235,7 @@ __global__ void __launch_bounds__(256) vr_gridmarch_kernel(const GridMarchParams
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&p.work.counters->path_samples, a);
         atomicAdd(&p.work.counters->density_lookups, b);
+        atomicAdd(&p.work.counters->voxel_loads, b);      // the grid marchers load a voxel per lookup
         atomicAdd(&p.work.counters->shadow_rays, c);
     }
 }

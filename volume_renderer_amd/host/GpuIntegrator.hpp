@@ -36,34 +36,44 @@ struct ThreadInfo {
     uint32_t toHeight;
 };
 
-// The SceneInfo members the path reads (Utils/Types.h:129-146), already resident on the GPU.
+// The SceneInfo members the path reads (Utils/Types.h:129-146), resident on every GPU of the list (the grid is
+// replicated: 288 GB of HBM each).  One GPU by default; with several, render() spreads the frame's rows over them as
+// BaseIntegrator::render spreads them over its worker threads (BaseIntegrator.cpp:143-181).
 class SceneInfo {
 public:
-    explicit SceneInfo(int hip_device = 0)
+    explicit SceneInfo(int hip_device = 0) : SceneInfo(std::vector<int>{ hip_device }) {}
+    explicit SceneInfo(const std::vector<int>& hip_devices)
     {
-        if (vr_backend_create(hip_device, &backend_) != VR_OK)
-            throw std::runtime_error(std::string("vr_backend_create: ") + vr_backend_last_error(nullptr));
+        if (vr_group_create(hip_devices.data(), (uint32_t)hip_devices.size(), &group_) != VR_OK)
+            throw std::runtime_error(std::string("vr_group_create: ") + vr_group_last_error(nullptr));
     }
-    ~SceneInfo() { vr_backend_destroy(backend_); }
+    ~SceneInfo() { vr_group_destroy(group_); }
     SceneInfo(const SceneInfo&) = delete;
     SceneInfo& operator=(const SceneInfo&) = delete;
 
     // densityGrid (+ temperatureGrid): SceneLoader.cpp:207-230
     void setDensity(const vr_grid_desc& density, const vr_grid_desc* temperature = nullptr)
     {
-        check(vr_backend_set_density(backend_, &density, temperature));
+        checkGroup(vr_group_set_density(group_, &density, temperature));
     }
     // scene + primitives + materials: SceneLoader.cpp:69-199
-    void setMesh(const vr_mesh_desc& mesh) { check(vr_backend_set_mesh(backend_, &mesh)); }
+    void setMesh(const vr_mesh_desc& mesh) { checkGroup(vr_group_set_mesh(group_, &mesh)); }
 
-    vr_backend* backend() const { return backend_; }
+    vr_backend_group* group() const { return group_; }
+    uint32_t deviceCount() const { return vr_group_size(group_); }
+    // the first GPU's backend: renderPartial, the reference's one-worker call, runs there
+    vr_backend* backend() const { return vr_group_backend(group_, 0); }
     void check(int rc) const
     {
-        if (rc != VR_OK) throw std::runtime_error(vr_backend_last_error(backend_));
+        if (rc != VR_OK) throw std::runtime_error(vr_backend_last_error(backend()));
+    }
+    void checkGroup(int rc) const
+    {
+        if (rc != VR_OK) throw std::runtime_error(vr_group_last_error(group_));
     }
 
 private:
-    vr_backend* backend_ = nullptr;
+    vr_backend_group* group_ = nullptr;
 };
 
 class BaseIntegrator {
@@ -82,11 +92,11 @@ public:
     }
 
     // BaseIntegrator::render up to the end of its timed span (BaseIntegrator.cpp:131-193): the
-    // float framebuffer before tonemap and save.  The caller owns `framebuffer`
-    // (options.width * options.height pixels), as render() owns its `new Vec3f[]`.
+    // float framebuffer before tonemap and save, rows i, i+N, ... on GPU i of the scene's N.  The caller owns
+    // `framebuffer` (options.width * options.height pixels), as render() owns its `new Vec3f[]`.
     void render(const Options& options, SceneInfo* scene, Vec3f* framebuffer)
     {
-        scene->check(vr_backend_render(scene->backend(), &options, id_, reinterpret_cast<float*>(framebuffer)));
+        scene->checkGroup(vr_group_render(scene->group(), &options, id_, reinterpret_cast<float*>(framebuffer)));
     }
 
     vr_integrator_id id() const { return id_; }
@@ -108,6 +118,9 @@ struct IntegratorFactory {
             { "nanoVDBEmission", VR_INTEGRATOR_NANOVDB_EMISSION },
             { "heterogeneousPerlinNoise", VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE },
             { "densitySampling", VR_INTEGRATOR_DENSITY_SAMPLING },
+            // no counterpart in the reference's factory: the trackers bounded by the mesh
+            { "meshRatioTracking", VR_INTEGRATOR_MESH_RATIO_TRACKING },
+            { "meshDeltaTracking", VR_INTEGRATOR_MESH_DELTA_TRACKING },
         };
         for (const auto& e : table)
             if (name == e.name) return std::make_unique<BaseIntegrator>(e.id);

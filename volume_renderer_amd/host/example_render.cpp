@@ -1,15 +1,23 @@
 // example_render.cpp — the reference's RenderScene() flow (RayTracer.cpp:11-20,
-// SceneRenderer.cpp:13-29) on the GPU backend, for a 64^3 test grid.  Build:
+// SceneRenderer.cpp:13-29) on the GPU backend, for a 64^3 test grid.  Arguments: the HIP device ordinals to render
+// on (default: 0); with several the frame's rows are spread over them (`example_render 0 1 2 3 4 5 6 7` on a node;
+// `example_render 0 0` rehearses two on a one-GPU box).  Prints the mean and a hash of the frame's bits: the frame
+// is the same for every device count.  Build:
 //   g++ -std=c++17 -O2 example_render.cpp -L../csrc -lvr_backend -Wl,-rpath,'$ORIGIN/../csrc' -o example_render
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "GpuIntegrator.hpp"
 
-int main()
+int main(int argc, char** argv)
 {
     using namespace vr_host;
+    std::vector<int> devices;
+    for (int a = 1; a < argc; ++a) devices.push_back(std::atoi(argv[a]));
+    if (devices.empty()) devices.push_back(0);
     const int n = 64;
     std::vector<float> vox((size_t)n * n * n);
     for (int i = 0; i < n; ++i)
@@ -26,7 +34,7 @@ int main()
     g.max_value = -1.f;
 
     try {
-        SceneInfo scene(0);
+        SceneInfo scene(devices);
         scene.setDensity(g);
         Options o = defaultOptions();
         o.width = o.widthReference = 256; o.height = o.heightReference = 256;
@@ -41,7 +49,15 @@ int main()
         renderer->render(o, &scene, fb.data());
         double sum = 0;
         for (const Vec3f& p : fb) sum += p.x + p.y + p.z;
+        uint64_t hash = 1469598103934665603ull;                       // FNV-1a over the frame's bit patterns
+        for (const Vec3f& p : fb) {
+            uint32_t w[3];
+            std::memcpy(w, &p, sizeof w);
+            for (uint32_t v : w) { hash ^= v; hash *= 1099511628211ull; }
+        }
+        std::printf("devices %u\n", scene.deviceCount());
         std::printf("mean channel value %.6f\n", sum / (3.0 * fb.size()));
+        std::printf("frame hash %016llx\n", (unsigned long long)hash);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;
