@@ -268,7 +268,10 @@ def test_tracking_fast_mode_tracks_the_oracle(backend, oracle, cloud64, integ):
     st = backend.last_stats()
     rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
     frac_close = np.mean(np.all(rel < 1e-4, axis=-1))
-    assert frac_close > 0.80, frac_close          # same streams: most pixels agree to rounding
+    print(f"integrator {integ}: {frac_close:.4f} of the pixels within 1e-4 of the oracle, {np.mean(np.all(rel < 1e-2, axis=-1)):.4f} within 1e-2")
+    # same streams, so nearly every pixel agrees to rounding (measured 99.80 % ratio, 99.98 % delta); the rest took
+    # another branch on a rounding tie (a roulette draw, a collision type) and are a different, equally valid sample
+    assert frac_close > (0.99 if integ == RATIO else 0.999), frac_close
     assert abs(got.mean() - want.mean()) / want.mean() < 5e-3
     assert abs(st["density_lookups"] - wst["density_lookups"]) / wst["density_lookups"] < 5e-3
 
@@ -497,6 +500,39 @@ def test_config4_size_properties(backend):
     medium = np.any(full != np.array(o.backgroundColor[:], dtype=np.float32), axis=2)
     assert 0.1 < medium.mean() < 0.9
     backend.generate_cloud(64, scenes.cloud_radius(64))                       # release the 4 GiB pair
+
+
+def test_nan_voxels_are_empty_space_on_the_gpu(backend, oracle, cloud64):
+    """DESIGN.md 9, a deliberate deviation: the reference's `if (sigma <= 0) continue` lets a NaN density through to the
+    collision code (the oracle restates that: with libm its ratio-tracking frame has NaN pixels); the GPU path treats
+    a NaN voxel as empty (`!(sigma > 0)`), so its frame is the frame of the grid with those voxels zeroed."""
+    vox = cloud64.voxels.copy()
+    dense = np.argwhere(vox > 0.0)               # also the thin outer shell: the shipped delta walks end within a voxel or two
+    for i, j, k in dense[::50]:
+        vox[i, j, k] = np.nan
+    nan_grid = Grid(vox, max_value=float(np.nanmax(vox)))
+    zero_grid = Grid(np.nan_to_num(vox, nan=0.0), max_value=float(np.nanmax(vox)))
+    backend.set_seed(scenes.SEED)
+    for integ in (RATIO, DELTA):
+        o = scenes.options_cloud(integ, 64, 48, 48, 4)
+        sc0, _k0 = ol.make_scene(density=zero_grid)
+        want, wst = oracle_image(oracle, sc0, o, integ)
+        scn, _kn = ol.make_scene(density=nan_grid)
+        oracle.vro_set_math_mode(ol.MATH_LIBM)              # the reference's arithmetic: libm's exp(NaN) is NaN
+        ref_like = ol.render(scn, o, integ, rng_mode=ol.RNG_PHILOX, seed=scenes.SEED)
+        # what the reference would have written: NaN pixels from the ratio tracker (transmission *= exp(-l * NaN));
+        # the delta tracker's sample does not contain the transmission, its NaN voxels scatter every time instead
+        assert np.isnan(ref_like).any() if integ == RATIO else \
+            not bitexact(ref_like, ol.render(sc0, o, integ, rng_mode=ol.RNG_PHILOX, seed=scenes.SEED))
+        backend.set_density(nan_grid)
+        for mode in (MODE_EXACT, MODE_EXACT_SKIP, MODE_FAST):
+            backend.set_mode(mode)
+            got = backend.render(o, integ)
+            assert np.isfinite(got).all(), mode
+            if mode != MODE_FAST:
+                assert bitexact(got, want), (integ, mode)
+                assert backend.last_stats()["density_lookups"] == wst["density_lookups"]
+    backend.set_density(cloud64)
 
 
 def test_errors_are_reported_not_thrown(backend, cloud64):
