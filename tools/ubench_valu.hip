@@ -6,6 +6,7 @@
 #include <cstdint>
 #define ITERS 4096
 #define UNROLL 16
+typedef float float2v __attribute__((ext_vector_type(2)));
 template <int OP> __global__ void __launch_bounds__(256) k(uint32_t* out, uint32_t seed)
 {
     uint32_t a[UNROLL]; float f[UNROLL];
@@ -26,6 +27,20 @@ template <int OP> __global__ void __launch_bounds__(256) k(uint32_t* out, uint32
             if (OP == 9) f[i] = fmaf(f[i], 0.999f, 0.001f);              // v_fma
             if (OP == 10) f[i] = floorf(f[i] * 1.5f);                    // mul + floor
             if (OP == 11) f[i] = sqrtf(f[i]) + 1.0f;                     // IEEE sqrt + add
+            if (OP == 15) f[i] = f[i] + 0.001f;                          // v_add_f32
+            if (OP == 16) f[i] = fminf(fmaxf(f[i], 0.5f), 1.5f) * 1.0001f;   // v_med3 / min+max, then a mul
+        }
+        if (OP >= 12 && OP <= 14) {
+            // packed fp32: two floats per lane and instruction.  Eight register pairs, one instruction each per pass
+#pragma unroll
+            for (int i = 0; i < UNROLL; i += 2) {
+                float2v v = { f[i], f[i + 1] };
+                const float2v c1 = { 0.999f, 0.998f }, c2 = { 0.001f, 0.002f };
+                if (OP == 12) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(v) : "v"(v), "v"(c1), "v"(c2));
+                if (OP == 13) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(c1));
+                if (OP == 14) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(c2));
+                f[i] = v.x; f[i + 1] = v.y;
+            }
         }
     }
     uint32_t r = 0;
@@ -41,7 +56,7 @@ template <int OP> void run(const char* name, uint32_t* d)
     hipEventRecord(e0); k<OP><<<blocks, 256>>>(d, 2); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     // per SIMD: 4 waves * ITERS * UNROLL statements
-    double stmts = 4.0 * ITERS * UNROLL;
+    double stmts = 4.0 * ITERS * (OP >= 12 && OP <= 14 ? UNROLL / 2 : UNROLL);   // packed: one instruction per register pair
     printf("%-28s %8.3f ms  %6.2f ns per wave-statement per SIMD  (~%.1f cycles @2.4GHz)\n", name, ms, ms * 1e6 / stmts, ms * 1e6 / stmts * 2.4);
 }
 int main()
@@ -50,5 +65,7 @@ int main()
     run<0>("xor+shift+xor", d); run<1>("v_mul_lo_u32", d); run<2>("v_mul_hi_u32", d); run<3>("mad_u64_u32 + xor", d);
     run<4>("mad_u32_u24", d); run<5>("rcp + add", d); run<6>("expf (mul,exp,mul)", d); run<7>("logf (log,mul,add)", d);
     run<8>("IEEE div + add", d); run<9>("fma", d); run<10>("mul + floor", d); run<11>("IEEE sqrt + add", d);
+    run<15>("v_add_f32", d); run<16>("clamp (med3) + mul", d);
+    run<12>("v_pk_fma_f32 (2 floats)", d); run<13>("v_pk_mul_f32 (2 floats)", d); run<14>("v_pk_add_f32 (2 floats)", d);
     return 0;
 }
