@@ -77,7 +77,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config2_ratio_1080p_64spp_cloud512", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--mode", default="fast", choices=["fast", "exact", "local"],
+                    help="local = VR_MODE_FAST_LOCAL: delta tracking over per-brick majorants (textbook regimes only; not the reference's estimator)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"], help="see the module docstring")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "on", "off"])
@@ -166,7 +167,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from volume_renderer_amd import MODE_EXACT, MODE_FAST, Backend, INTEGRATORS
+    from volume_renderer_amd import MODE_EXACT, MODE_FAST, MODE_FAST_LOCAL, Backend, INTEGRATORS
     from volume_renderer_amd import workloads as scenes
     from volume_renderer_amd.abi import copy_options
 
@@ -178,7 +179,7 @@ def main():
     mesh_tracker = integ.startswith("mesh")
 
     be = Backend(local)
-    be.set_mode(MODE_EXACT if a.mode == "exact" else MODE_FAST)
+    be.set_mode({"exact": MODE_EXACT, "local": MODE_FAST_LOCAL}.get(a.mode, MODE_FAST))
     be.set_seed(scenes.SEED)
     mesh = None
     if mesh_scene:

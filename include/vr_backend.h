@@ -35,7 +35,15 @@ enum {
     VR_MODE_FAST = 1,
     /* EXACT arithmetic with FAST's batched empty-space stepping: must also be bit-identical to
      * the oracle; exists so that tests can pin the batching on its own. */
-    VR_MODE_EXACT_SKIP = 2
+    VR_MODE_EXACT_SKIP = 2,
+    /* FAST, and deltaTracking sampled against PER-BRICK majorants (a coarse majorant grid walked by a 3-D DDA)
+     * instead of the reference's single global one (IntegratorDeltaTracking.cpp:44-47).  Opt-in, and NOT the
+     * reference's estimator: it is textbook delta tracking (the density is looked up at the tentative collision,
+     * not one free path earlier), offered only where the reference's own parameters make it a plain delta
+     * tracker — stepSizeMultiplier 1, stepSizeMin <= 0.01, stepSizeMax >= 1e4, no importance-sampling output —
+     * else VR_ERR_UNSUPPORTED.  Statistically equal to FAST up to the smear of one free path; every other
+     * integrator renders exactly as in VR_MODE_FAST. */
+    VR_MODE_FAST_LOCAL = 3
 };
 
 /* ---- life cycle -------------------------------------------------------------------------

@@ -14,6 +14,7 @@ from .abi import GridDesc, MeshDesc, OptionsPod, RenderStats
 MODE_EXACT = 0
 MODE_FAST = 1
 MODE_EXACT_SKIP = 2
+MODE_FAST_LOCAL = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvr_backend.so")

@@ -21,6 +21,7 @@
 
 using namespace vr;
 
+#define VR_MAJOR_LEVELS 5   // majorant cells of 8^3 (the bricks) ... 128^3 voxels
 #define VR_SKIP_CAP 31   // largest empty-cube radius the skip grid records, in voxels
 
 namespace {
@@ -249,6 +250,8 @@ struct vr_backend {
     // density / temperature
     bool     has_density = false, has_temperature = false;
     float*   d_bricks = nullptr;  float* d_skip = nullptr;  GridDev grid{};   // d_skip: see k_skip_pass
+    float*   d_major = nullptr;                                                // per-brick maximum, then the same pooled over 2^3 ... 16^3 bricks (vr_delta_dda_kernel)
+    size_t   major_off[VR_MAJOR_LEVELS] = {}; int32_t major_nc[VR_MAJOR_LEVELS][3] = {};          // offset and cell counts of each level
     float*   d_tbricks = nullptr; GridDev tgrid{};
     float    inv_mat[9]{}, vec[3]{}, mat[9]{};
     float    bmin[3]{}, bmax1[3]{};
@@ -278,7 +281,7 @@ struct vr_backend {
     unsigned char*    d_noalloc = nullptr;
 
     // developer knobs (VR_TUNE_*), read at the start of each render call; 0 = built-in default
-    int tune_tile_h_log = 0, tune_round_max = 0, tune_round_events = 0, tune_chunk = 0, tune_march_tile_h_log = 0, tune_bvh_leaf = 0;
+    int tune_tile_h_log = 0, tune_round_max = 0, tune_round_events = 0, tune_chunk = 0, tune_march_tile_h_log = 0, tune_bvh_leaf = 0, tune_major_level = 0;
     // hipOccupancyMaxActiveBlocksPerMultiprocessor per kernel, asked once
     struct { const void* kernel; int blocks; } occupancy[64]{};
     int noccupancy = 0;
@@ -366,19 +369,46 @@ int build_derived(vr_backend* b)
     const GridDev& g = b->grid;
     const uint32_t nbricks = (uint32_t)g.nb[0] * g.nb[1] * g.nb[2];
     const size_t   total = (size_t)nbricks * 512;
-    float* d_major = nullptr;
-    HIP_TRY(b, hipMalloc((void**)&d_major, (size_t)nbricks * sizeof(float)));
+    if (b->d_major) { (void)hipFree(b->d_major); b->d_major = nullptr; }
+    // kept: the coarse majorant grids of the local-majorant delta tracker (level 0 = bricks, levels 1, 2 pooled below)
+    size_t major_total = 0;
+    for (int l = 0; l < VR_MAJOR_LEVELS; ++l) {
+        b->major_off[l] = major_total;
+        for (int a = 0; a < 3; ++a) b->major_nc[l][a] = (g.nb[a] + (1 << l) - 1) >> l;
+        major_total += (size_t)b->major_nc[l][0] * b->major_nc[l][1] * b->major_nc[l][2];
+    }
+    HIP_TRY(b, hipMalloc((void**)&b->d_major, major_total * sizeof(float)));
+    float* const d_major = b->d_major;
     k_majorant<<<(nbricks + 3) / 4, 256, 0, b->stream>>>(b->d_bricks, d_major, nbricks);
     hipError_t e = hipGetLastError();
     std::vector<float> h(nbricks);
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_major, (size_t)nbricks * sizeof(float), hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    (void)hipFree(d_major);
     if (e != hipSuccess) return fail(b, VR_ERR_HIP, "majorant: %s", hipGetErrorString(e));
     // padding voxels hold the background, which getExtrema also sees for inactive voxels inside the bbox
     float m = h[0];
     for (uint32_t i = 1; i < nbricks; ++i) if (h[i] > m) m = h[i];
     b->max_value = m;
+    {   // levels 1..4: maxima over 2^3 ... 16^3 bricks (on the host: at most 2^21 bricks)
+        std::vector<float> lv(major_total - nbricks);
+        for (int l = 1; l < VR_MAJOR_LEVELS; ++l) {
+            const int* nc = b->major_nc[l];
+            float* out = lv.data() + (b->major_off[l] - nbricks);
+            for (int i = 0; i < nc[0]; ++i)
+                for (int j = 0; j < nc[1]; ++j)
+                    for (int k = 0; k < nc[2]; ++k) {
+                        float mx = -INFINITY;
+                        for (int di = 0; di < (1 << l); ++di)
+                            for (int dj = 0; dj < (1 << l); ++dj)
+                                for (int dk = 0; dk < (1 << l); ++dk) {
+                                    const int bi = (i << l) + di, bj = (j << l) + dj, bk = (k << l) + dk;
+                                    if (bi < g.nb[0] && bj < g.nb[1] && bk < g.nb[2]) mx = std::max(mx, h[((size_t)bi * g.nb[1] + bj) * g.nb[2] + bk]);
+                                }
+                        out[((size_t)i * nc[1] + j) * nc[2] + k] = mx;
+                    }
+        }
+        if (!lv.empty()) HIP_TRY(b, hipMemcpy(b->d_major + nbricks, lv.data(), lv.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
 
     if (b->d_skip) { (void)hipFree(b->d_skip); b->d_skip = nullptr; }
     uint8_t *d_a = nullptr, *d_b = nullptr;
@@ -525,6 +555,7 @@ void read_knobs(vr_backend* b)
     auto plus1 = [](const char* name) { const char* v = getenv(name); return v && *v ? atoi(v) + 1 : 0; };   // 0 is a valid value
     b->tune_tile_h_log = plus1("VR_TUNE_TILE_H_LOG");
     b->tune_march_tile_h_log = plus1("VR_TUNE_MARCH_TILE_H_LOG");
+    b->tune_major_level = plus1("VR_TUNE_MAJORANT_LEVEL");
     b->tune_round_max = tune_env("VR_TUNE_ROUND_MAX"); b->tune_round_events = tune_env("VR_TUNE_ROUND_EVENTS");
     b->tune_chunk = tune_env("VR_TUNE_CHUNK"); b->tune_bvh_leaf = tune_env("VR_TUNE_BVH_LEAF");
 }
@@ -578,6 +609,15 @@ int validate(vr_backend* b, const vr_options_pod* o, int integrator)
             return fail(b, VR_ERR_INVALID_ARG, "stepSize min %g is below float resolution at ray parameter %g", o->stepSizeMin, tmax);
         if (std::sqrt(diag) / o->stepSizeMin > 1.0e8f)
             return fail(b, VR_ERR_INVALID_ARG, "stepSize min %g needs more than 1e8 steps across the grid", o->stepSizeMin);
+        if (b->mode == VR_MODE_FAST_LOCAL && integrator == VR_INTEGRATOR_DELTA_TRACKING) {
+            // per-brick majorants change the reference's estimator wherever it scales or clamps its free paths
+            if (o->stepSizeMultiplier != 1.0f || o->stepSizeMin > 0.01f || o->stepSizeMax < 1.0e4f)
+                return fail(b, VR_ERR_UNSUPPORTED, "VR_MODE_FAST_LOCAL needs the textbook regime (stepSizeMultiplier 1, stepSizeMin <= 0.01, "
+                            "stepSizeMax >= 1e4): with scaled or clamped free paths the reference is not a delta tracker and local "
+                            "majorants would change its image");
+            if (o->useImportanceSampling) return fail(b, VR_ERR_UNSUPPORTED, "VR_MODE_FAST_LOCAL does not track the path pdf (useImportanceSampling)");
+            if (!(o->lightRayDensityMultiplier >= 0.0f)) return fail(b, VR_ERR_UNSUPPORTED, "VR_MODE_FAST_LOCAL needs lightRayDensityMultiplier >= 0");
+        }
     } else {
         if (!b->has_mesh) return fail(b, VR_ERR_NO_MESH, "marching integrators need a mesh");
     }
@@ -690,7 +730,8 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
     b->last_counters = d_counters;
     b->passes_used = 0;
     b->launches = 0;
-    const bool exact = b->mode != VR_MODE_FAST;
+    const bool exact = b->mode != VR_MODE_FAST && b->mode != VR_MODE_FAST_LOCAL;
+    const bool local_majorants = b->mode == VR_MODE_FAST_LOCAL && integrator == VR_INTEGRATOR_DELTA_TRACKING;
     const bool timed = !noalloc;
 
     for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)per_pass) {
@@ -756,6 +797,32 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             }
             k_store_cold<<<1, 64, 0, b->stream>>>(cold, d_cold);
             HIP_TRY(b, hipGetLastError());
+            if (local_majorants) {
+                DdaParams dp{};
+                dp.cold = d_cold; dp.work = work;
+                dp.density = b->grid;
+                // majorant cells of 32^3 voxels (level 2) by default: measured 2128 / 2591 / 2725 / 2350 / 1627 M samples/s for levels 0-4 on
+                // config 3 textbook and 1336 / 1720 / 1898 / 1812 / 1421 on config 4 (VR_TUNE_MAJORANT_LEVEL; 0 = the 8^3 bricks)
+                // (a sixteenth of the grid's largest extent, between 8 and 32 voxels: small grids keep the bricks)
+                const int maxdim = std::max(b->grid.dim[0], std::max(b->grid.dim[1], b->grid.dim[2]));
+                const int auto_level = maxdim >= 512 ? 2 : (maxdim >= 256 ? 1 : 0);
+                const int level = b->tune_major_level > 0 ? std::min(b->tune_major_level - 1, VR_MAJOR_LEVELS - 1) : auto_level;
+                dp.major = b->d_major + b->major_off[level]; dp.cell_log = 3 + level;
+                for (int a = 0; a < 3; ++a) dp.nc[a] = b->major_nc[level][a];
+                dp.sigma_a = o->sigma_a; dp.sigma_s = o->sigma_s; dp.light_mult = o->lightRayDensityMultiplier;
+                dp.round_max = tuned(b->tune_round_max, 64); dp.round_events = tuned(b->tune_round_events, 16);
+                void (*dk)(const DdaParams) = b->has_temperature ? vr_delta_dda_kernel<true> : vr_delta_dda_kernel<false>;
+                int per_cu = 8;
+                rc = launch_cap(b, dk, dp, per_cu);
+                if (rc) return rc;
+                const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_cu * b->num_cu, (work.nitems + 255ull) / 256));
+                const uint64_t fair = work.nitems / ((uint64_t)blocks * 4 * 8);
+                dp.work.chunk = (uint32_t)std::min<uint64_t>((uint64_t)tuned(b->tune_chunk, 128), std::max<uint64_t>(64, fair & ~63ull));
+                if (timed) HIP_TRY(b, hipEventRecord(ev.e0, b->stream));
+                hipLaunchKernelGGL(dk, dim3(blocks), dim3(256), 0, b->stream, dp);
+                HIP_TRY(b, hipGetLastError());
+                if (timed) HIP_TRY(b, hipEventRecord(ev.e1, b->stream));
+            } else {
             TrackParams p{};
             p.cold = d_cold; p.work = work;
             p.density = b->grid;
@@ -782,13 +849,14 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             // empty-space runs read the skip grid, whose empty voxels only keep the sign of sigma for
             // multipliers >= 0 (the shadow multiplier is only read by the ratio tracker)
             const bool skip_ok = span_ok && o->lightRayDensityMultiplier >= 0.0f && (!ratio || o->shadowRayDensityMultiplier >= 0.0f);
-            if (skip_ok && b->mode != VR_MODE_EXACT) p.density.bricks = b->d_skip;
+            if (skip_ok && b->mode != VR_MODE_EXACT) p.density.bricks = b->d_skip;   // (FAST_LOCAL renders the other integrators as FAST)
 #define VR_TK5(I, E, S, Q, T, N) (mesh_bound ? vr_track_kernel<I, E, S, Q, T, N, true> : vr_track_kernel<I, E, S, Q, T, N, false>)
 #define VR_TK4(I, E, S, Q) (temp ? (span ? VR_TK5(I, E, S, Q, true, true) : VR_TK5(I, E, S, Q, true, false)) \
                                  : (span ? VR_TK5(I, E, S, Q, false, true) : VR_TK5(I, E, S, Q, false, false)))
 #define VR_TRACK_KERNEL(E, S) (ratio ? (is ? VR_TK4(INTEG_RATIO, E, S, true) : VR_TK4(INTEG_RATIO, E, S, false)) \
                                      : (is ? VR_TK4(INTEG_DELTA, E, S, true) : VR_TK4(INTEG_DELTA, E, S, false)))
-            switch (skip_ok ? b->mode : (b->mode == VR_MODE_FAST ? -1 : VR_MODE_EXACT)) {
+            const int kmode = b->mode == VR_MODE_FAST_LOCAL ? VR_MODE_FAST : b->mode;   // (only the plain delta tracker has a local-majorant kernel)
+            switch (skip_ok ? kmode : (kmode == VR_MODE_FAST ? -1 : VR_MODE_EXACT)) {
             case -1:                 kern = VR_TRACK_KERNEL(false, false); break;
             case VR_MODE_EXACT:      kern = VR_TRACK_KERNEL(true, false); break;
             case VR_MODE_EXACT_SKIP: kern = VR_TRACK_KERNEL(true, true); break;
@@ -810,6 +878,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, b->stream, p);
             HIP_TRY(b, hipGetLastError());
             if (timed) HIP_TRY(b, hipEventRecord(ev.e1, b->stream));
+            }
         } else {
             MarchParams p{};
             p.cam = cam; p.work = work;
@@ -919,7 +988,7 @@ void vr_backend_destroy(vr_backend* b)
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    void* ptrs[] = { b->d_bricks, b->d_skip, b->d_tbricks, b->d_nodes, b->d_tris, b->d_p2s, b->d_dissolve, b->d_diffuse, b->d_samples,
+    void* ptrs[] = { b->d_bricks, b->d_skip, b->d_major, b->d_tbricks, b->d_nodes, b->d_tris, b->d_p2s, b->d_dissolve, b->d_diffuse, b->d_samples,
                      b->d_rows, b->d_offsets, b->d_work, b->d_counters, b->d_maxbits, b->d_cold };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (Pass& p : b->passes) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -930,7 +999,8 @@ void vr_backend_destroy(vr_backend* b)
 int vr_backend_set_mode(vr_backend* b, int mode)
 {
     if (!b) return VR_ERR_INVALID_ARG;
-    if (mode != VR_MODE_EXACT && mode != VR_MODE_FAST && mode != VR_MODE_EXACT_SKIP) return fail(b, VR_ERR_INVALID_ARG, "unknown mode %d", mode);
+    if (mode != VR_MODE_EXACT && mode != VR_MODE_FAST && mode != VR_MODE_EXACT_SKIP && mode != VR_MODE_FAST_LOCAL)
+        return fail(b, VR_ERR_INVALID_ARG, "unknown mode %d", mode);
     b->mode = mode;
     return VR_OK;
 }

@@ -869,6 +869,262 @@ vr_track_kernel(const TrackParams p)
 }
 
 // =============================================================================================
+// delta tracking over per-brick majorants (VR_MODE_FAST_LOCAL) — NOT the reference's estimator
+// =============================================================================================
+// north_star "DensityFields": a coarse majorant grid and DDA traversal with tight per-cell bounds.  The reference
+// samples every free path against ONE majorant, max(density) * (sigma_a + sigma_s) (IntegratorDeltaTracking.cpp:44-47),
+// so in a cloud whose density is mostly far below its maximum nearly every tentative collision is a null one.  Here
+// the ray walks the grid's 8^3 bricks (3-D DDA) and samples its free path against the brick's own maximum: a free
+// path that ends beyond the brick is cut at the brick's exit and drawn again there (the exponential is memoryless),
+// an empty brick is crossed in one step, and the density is looked up AT the tentative collision.  That is textbook
+// delta tracking — unbiased for any field — whereas the reference decides a collision with the density it looked up
+// one free path EARLIER (:55, :74, :84-98) and clamps / scales its free paths (:63-65).  So this mode is offered only
+// where the reference's own parameters make it a plain delta tracker (stepSizeMultiplier 1, clamps out of reach: the
+// "textbook" regime of SURVEY 7(ii), BASELINE configs 3-textbook and 4), it is opt-in, and its parity is statistical:
+// exp(-tau) on slabs, layered ones included, and agreement with the global-majorant kernel within the smear of one
+// free path (tests/test_gpu_local_majorant.py).
+struct DdaParams {
+    const TrackCold* cold;
+    WorkDev          work;
+    GridDev          density;
+    const float*     major;          // per majorant cell: max over its voxels
+    int32_t          cell_log;       // a majorant cell is (1 << cell_log)^3 voxels: 3 = the 8^3 bricks, 4 or 5 = 2^3 or 4^3 bricks
+    int32_t          nc[3];          // cells per axis
+    float            sigma_a, sigma_s, light_mult;
+    int32_t          round_max, round_events;
+};
+enum { DD_NEED = 0, DD_WALK = 1, DD_EXHAUSTED = 2, DD_SCATTER = 3, DD_ABSORBED = 4, DD_ESCAPED = 5, DD_BLACK = 6 };
+
+template <bool TEMP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+vr_delta_dda_kernel(const DdaParams p)
+{
+    typedef Math<false> M;
+    const int      lane = threadIdx.x & 63;
+    const uint32_t k0 = p.work.key0, k1 = p.work.key1;
+    const float    sig_t = p.sigma_a + p.sigma_s;
+    const float    mu_scale = p.light_mult * sig_t;                   // brick maximum -> majorant of mu_t in the brick
+
+    uint32_t st = DD_NEED;
+    f3       eye = mk3(0, 0, 0), dir = mk3(0, 0, 1);                  // the index-space ray of the walk
+    float    t = 0, t1 = 0;
+    float    tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;    // DDA: parameter of the next brick face per axis, and per brick
+    int32_t  bi = 0, bj = 0, bk = 0;                                  // current brick
+    float    mu = 0;                                                  // majorant of the current brick
+    uint32_t xs0 = 1, xs1 = 0, xs2 = 0, xs3 = 0;
+    __shared__ float s_ev[8][256];                                    // what only the event code touches
+    float* const ev = &s_ev[0][threadIdx.x];
+    LdsF3     wdir{ev};                                               // data->rayDirection
+    uint32_t& item = *(uint32_t*)(ev + 3 * 256);
+    uint32_t& rng_pixel = *(uint32_t*)(ev + 4 * 256);
+    uint32_t& rng_ts = *(uint32_t*)(ev + 5 * 256);
+    int&      depth_remaining = *(int*)(ev + 6 * 256);
+    float&    absorbed_mu_a = ev[7 * 256];
+    uint32_t  steps = 0;
+    unsigned long long n_lookups = 0, w_trips = 0, w_trip_lanes = 0, w_phases = 0;
+    uint32_t n_paths = 0, n_scatter = 0, n_limit = 0;
+    uint32_t chunk_next = 0, chunk_end = 0, strip_try = 0, strip_lo = 0, strip_w = 0;
+    bool     chunk_dry = false;
+
+    auto seed_stream = [&]() {
+        philox4x32_10(rng_pixel, rng_ts & 0xfffffu, (rng_ts >> 20) & 0xffu, 0u, k0, k1, xs0, xs1, xs2, xs3);
+        if ((xs0 | xs1 | xs2 | xs3) == 0u) xs0 = 1u;
+    };
+    // the DDA's state for cell (i, j, k) of the current ray: parameters of its far faces, per-cell increments, majorant
+    const int32_t cl = p.cell_log;
+    const float   cs = (float)(1 << cl);
+    auto enter_brick = [&](int32_t i, int32_t j, int32_t k) {
+        bi = i; bj = j; bk = k;
+        const f3 e = eye, d = dir;
+        const float inf = __builtin_huge_valf();
+        const float ix = d.x != 0 ? __builtin_amdgcn_rcpf(d.x) : inf, iy = d.y != 0 ? __builtin_amdgcn_rcpf(d.y) : inf,
+                    iz = d.z != 0 ? __builtin_amdgcn_rcpf(d.z) : inf;
+        tdx = cs * fabsf(ix); tdy = cs * fabsf(iy); tdz = cs * fabsf(iz);
+        tmx = d.x != 0 ? ((float)(p.density.min[0] + ((i + (d.x > 0 ? 1 : 0)) << cl)) - e.x) * ix : inf;
+        tmy = d.y != 0 ? ((float)(p.density.min[1] + ((j + (d.y > 0 ? 1 : 0)) << cl)) - e.y) * iy : inf;
+        tmz = d.z != 0 ? ((float)(p.density.min[2] + ((k + (d.z > 0 ? 1 : 0)) << cl)) - e.z) * iz : inf;
+        mu = p.major[((uint32_t)i * (uint32_t)p.nc[1] + (uint32_t)j) * (uint32_t)p.nc[2] + (uint32_t)k] * mu_scale;
+    };
+    // start a walk along (e, d) over [a, b]: the cell of its first point
+    auto set_ray = [&](f3 e, f3 d, float a, float b) {
+        eye = e; dir = d; t = a; t1 = b;
+        const f3 q = ray_at(e, d, a);
+        const int32_t nb0 = p.nc[0], nb1 = p.nc[1], nb2 = p.nc[2];
+        int32_t i = (floor_to_int(q.x) - p.density.min[0]) >> cl, j = (floor_to_int(q.y) - p.density.min[1]) >> cl,
+                k = (floor_to_int(q.z) - p.density.min[2]) >> cl;
+        i = i < 0 ? 0 : (i >= nb0 ? nb0 - 1 : i);     // the first point lies ON the bbox: rounding may put it a voxel outside
+        j = j < 0 ? 0 : (j >= nb1 ? nb1 - 1 : j);
+        k = k < 0 ? 0 : (k >= nb2 ? nb2 - 1 : k);
+        enter_brick(i, j, k);
+    };
+
+    for (;;) {
+        // =========================== event phase ===========================
+        w_phases++;
+        if (__any(st >= DD_SCATTER)) {
+            const TrackCold* c = opaque(p.cold);
+            if (st == DD_SCATTER) {
+                // IntegratorDeltaTracking.cpp:115-158: a new direction from the phase function, the walk goes on from
+                // the collision point
+                n_scatter++;
+                depth_remaining--;
+                rng_ts += 1u << 20;
+                seed_stream();
+                const uint32_t h0 = xoshiro128p_next(xs0, xs1, xs2, xs3), h1 = xoshiro128p_next(xs0, xs1, xs2, xs3);
+                const f3 scattered = hg_sample<false>(c->g, wdir, in_range(h0, 0.0f, 0.9999f), in_range(h1, 0.0f, 0.9999f));   // :124-127
+                const f3 point = ray_at(eye, dir, t);                                         // :130
+                wdir = scattered;                                                             // :146
+                float c0 = 1e-5f, c1 = VR_FLT_MAX;
+                if (!ray_clip<false>(point, scattered, c0, c1, c->bmin, c->bmax1)) st = DD_BLACK;   // :150-155 "scattering failed"
+                else if (depth_remaining <= 0) st = DD_ESCAPED;                               // :54, :175
+                else { st = DD_WALK; set_ray(point, scattered, c0, c1); }
+            }
+            if (st >= DD_ABSORBED) {
+                f3 colour = mk3(0, 0, 0);
+                if (st == DD_ESCAPED) colour = mk3(c->background[0], c->background[1], c->background[2]);   // :175
+                if (st == DD_ABSORBED) {                                                      // :101-113
+                    colour = mk3(c->medium[0], c->medium[1], c->medium[2]);
+                    if (TEMP) colour = add3(scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), absorbed_mu_a), colour);
+                }
+                n_lookups += steps; steps = 0;
+                store_sample(p.work.samples, item, colour);
+                st = DD_NEED;
+            }
+        }
+        // refill (the tracking kernel's work order: 8x8-pixel tiles, sub-samples of a tile together, one strip of tile
+        // columns per XCD, tile rows from the middle of the frame outwards)
+        for (;;) {
+            const bool               want = st == DD_NEED;
+            const unsigned long long need = __ballot(want);
+            if (need == 0ull) break;
+            const TrackCold* c = opaque(p.cold);
+            if (chunk_next == chunk_end) {
+                if (chunk_dry) { if (want) st = DD_EXHAUSTED; break; }
+                const uint32_t tiles_x = (c->cam.width + (64u >> c->tile_h_log) - 1u) >> (6u - c->tile_h_log);
+                const uint32_t tiles_y = (c->cam.nrows + (1u << c->tile_h_log) - 1u) >> c->tile_h_log;
+                bool got = false;
+                while (strip_try < VR_TRACK_STRIPS) {
+                    const uint32_t strip = ((blockIdx.x & 7u) + strip_try) % VR_TRACK_STRIPS;
+                    strip_lo = tiles_x * strip / VR_TRACK_STRIPS;
+                    strip_w = tiles_x * (strip + 1u) / VR_TRACK_STRIPS - strip_lo;
+                    const uint32_t strip_items = strip_w * tiles_y * c->cam.s_count * 64u;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(p.work.counter + strip * 8u, p.work.chunk);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base < strip_items) {
+                        chunk_next = base;
+                        chunk_end = base + p.work.chunk < strip_items ? base + p.work.chunk : strip_items;
+                        got = true;
+                        break;
+                    }
+                    strip_try++;
+                }
+                if (!got) { chunk_dry = true; continue; }
+            }
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            const uint32_t avail = chunk_end - chunk_next, asked = (uint32_t)__popcll(need);
+            const uint32_t first = chunk_next;
+            chunk_next += asked < avail ? asked : avail;
+            if (want && rank < avail) {
+                const uint32_t mine = first + rank;
+                const uint32_t th_log = c->tile_h_log, tw_log = 6u - th_log;
+                const uint32_t tile = mine >> 6, l = mine & 63u;
+                const uint32_t sl = tile % c->cam.s_count;
+                const uint32_t q = tile / c->cam.s_count;
+                const uint32_t tx = strip_lo + q % strip_w;
+                const uint32_t k = q / strip_w;
+                const uint32_t tiles_y = (c->cam.nrows + (1u << th_log) - 1u) >> th_log;
+                const uint32_t ty = (k & 1u) ? tiles_y / 2 - (k + 1) / 2 : tiles_y / 2 + k / 2;
+                const uint32_t x = (tx << tw_log) + (l & ((1u << tw_log) - 1u)), r = (ty << th_log) + (l >> tw_log);
+                if (x >= c->cam.width || r >= c->cam.nrows) continue;   // padding of the last tile column / row
+                item = (sl * c->cam.nrows + r) * c->cam.width + x;
+                const uint32_t s = c->cam.s_first + sl;
+                const uint32_t ci = c->cam.x0 + x;
+                const uint32_t cj = c->cam.y0 + c->cam.row_first + r * c->cam.row_stride;
+                n_paths++;
+                // castRay prologue                      IntegratorDeltaTracking.cpp:13-52
+                const f3 wd = primary_direction<false>(c->cam, ci, cj, s);
+                wdir = wd;
+                const f3 weye = mk3(c->cam.pos[0], c->cam.pos[1], c->cam.pos[2]);
+                const f3 ieye = mat_mult(c->inv_mat, mk3(weye.x - c->vec[0], weye.y - c->vec[1], weye.z - c->vec[2]));
+                const f3 idir = mat_mult(c->inv_mat, wd);
+                const float length = M::sqrt_(idir.x * idir.x + idir.y * idir.y + idir.z * idir.z);
+                const float inv_length = M::rcp_(length);
+                const f3 ndir = mk3(inv_length * idir.x, inv_length * idir.y, inv_length * idir.z);
+                float c0 = length * 1e-5f, c1 = VR_FLT_MAX;
+                if (!ray_clip<false>(ieye, ndir, c0, c1, c->bmin, c->bmax1) || c->max_depth == 0) {
+                    store_sample(p.work.samples, item, mk3(c->background[0], c->background[1], c->background[2]));   // :37-39
+                } else {
+                    st = DD_WALK;
+                    depth_remaining = (int)c->max_depth;
+                    rng_pixel = (cj << 16) | ci; rng_ts = s; steps = 0;
+                    seed_stream();
+                    set_ray(ieye, ndir, c0, c1);
+                }
+            }
+        }
+        if (!__any(st == DD_WALK)) break;
+
+        // =========================== step loop ===========================
+        if (st == DD_WALK && steps > p.work.step_limit) { n_limit++; st = DD_BLACK; }
+#pragma unroll 1
+        for (int it = 0; it < p.round_max; ++it) {
+            if (st == DD_WALK) {
+                // the brick's far face (or the end of the ray)
+                const float tface = fminf(fminf(tmx, tmy), tmz);
+                const float te = fminf(tface, t1);
+                float t_next = __builtin_huge_valf();
+                uint32_t w_event = 0;
+                if (mu > 0.0f) {
+                    const uint32_t w_path = xoshiro128p_next(xs0, xs1, xs2, xs3);
+                    w_event = xoshiro128p_next(xs0, xs1, xs2, xs3);
+                    const float u = fmaf((float)(w_path >> 8), (1.0f - 0.00001f) / 16777216.0f, 0.00001f);   // getFloat(0.00001, 1), :63
+                    t_next = fmaf(__builtin_amdgcn_logf(u), -0.6931471805599453f * __builtin_amdgcn_rcpf(mu), t);
+                }
+                if (!(t_next < te)) {
+                    // no collision inside this brick: on to the next one
+                    t = te;
+                    if (tface >= t1) st = DD_ESCAPED;                                         // :77-79 the ray has left the grid
+                    else {
+                        if (tmx <= tmy && tmx <= tmz) { bi += dir.x > 0 ? 1 : -1; tmx += tdx; }
+                        else if (tmy <= tmz)          { bj += dir.y > 0 ? 1 : -1; tmy += tdy; }
+                        else                          { bk += dir.z > 0 ? 1 : -1; tmz += tdz; }
+                        if ((uint32_t)bi >= (uint32_t)p.nc[0] || (uint32_t)bj >= (uint32_t)p.nc[1] || (uint32_t)bk >= (uint32_t)p.nc[2])
+                            st = DD_ESCAPED;                                                  // (rounding: the last face and t1 coincide)
+                        else mu = p.major[((uint32_t)bi * (uint32_t)p.nc[1] + (uint32_t)bj) * (uint32_t)p.nc[2] + (uint32_t)bk] * mu_scale;
+                    }
+                } else {
+                    // tentative collision at t_next: real with probability mu_t(x) / mu
+                    t = t_next;
+                    steps++;
+                    const float sigma = p.light_mult * grid_value_nocache(p.density, ray_at(eye, dir, t));   // :55, at the collision
+                    const float thr = (float)(w_event >> 8) * (1.0f / 16777216.0f) * mu;
+                    const float mu_a = sigma * p.sigma_a;
+                    if (thr < mu_a) { absorbed_mu_a = mu_a; st = DD_ABSORBED; }              // :101-113
+                    else if (thr < sigma * sig_t) st = DD_SCATTER;                            // :115
+                }
+            }
+            const int n_walk = __popcll(__ballot(st == DD_WALK));
+            w_trips++; w_trip_lanes += (unsigned)n_walk;
+            const int n_event = __popcll(__ballot(st >= DD_SCATTER));
+            if (n_event >= p.round_events || n_walk == 0) break;
+        }
+    }
+
+    unsigned long long a = wave_sum(n_paths), b = wave_sum(n_lookups), c = wave_sum(n_scatter), e = wave_sum(n_limit);
+    if (lane == 0) {
+        atomicAdd(&p.work.counters->path_samples, a);
+        atomicAdd(&p.work.counters->density_lookups, b);
+        atomicAdd(&p.work.counters->voxel_loads, b);
+        atomicAdd(&p.work.counters->scatter_events, c);
+        if (e) atomicAdd(&p.work.counters->step_limit_hits, e);
+        atomicAdd(&p.work.counters->wave_trips, w_trips);
+        atomicAdd(&p.work.counters->wave_trip_lanes, w_trip_lanes);
+        atomicAdd(&p.work.counters->event_phases, w_phases);
+    }
+}
+
+// =============================================================================================
 // mesh-bounded fixed-step marchers
 // =============================================================================================
 
