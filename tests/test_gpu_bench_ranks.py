@@ -41,3 +41,33 @@ def test_two_ranks_weak_and_strong():
     assert weak["lookups_per_sample"] == one["lookups_per_sample"]
     for d in (one, weak, strong):
         assert d["value"] > 0 and d["roofline"]["launches"] == d["n_gpus"]
+
+
+def test_two_real_gpus_rccl_and_peer_copies():
+    """On a box with at least two GPUs (the round-end node; the one-GPU test box skips): bench.py's N = 2 path over RCCL
+    without the rehearsal switch, and one frame over two devices behind the C-ABI (peer copies into the first GPU)."""
+    import numpy as np
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("VR_BENCH_REHEARSAL", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "small", "--cpu-baseline", "off"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and "RCCL" in two["config"]["partition"] and two["weak_scaling"]["value"] > 0
+    from volume_renderer_amd import MODE_FAST, Backend, BackendGroup
+    from volume_renderer_amd import workloads as wl
+    o = wl.options_cloud("ratioTracking", 64, 96, 50, 4)
+    with Backend(0) as one:
+        one.generate_cloud(64, wl.cloud_radius(64)); one.set_seed(wl.SEED); one.set_mode(MODE_FAST)
+        want = one.render(o, "ratioTracking")
+    with BackendGroup([0, 1]) as g:
+        g.generate_cloud(64, wl.cloud_radius(64)); g.set_seed(wl.SEED); g.set_mode(MODE_FAST)
+        assert np.array_equal(g.render(o, "ratioTracking"), want)
+        frame = torch.zeros((50, 96, 3), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        g.render_device(o, "ratioTracking", frame.data_ptr())
+        assert np.array_equal(frame.cpu().numpy(), want)
