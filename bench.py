@@ -15,7 +15,10 @@ Scaling over N GPUs (--scaling):
          spp x N samples per pixel (every GPU keeps its sample count).
   weak   only the weak measurement, as the line's value.  At N = 1 both ARE the named configuration.
 The timed step ends with the gathered frame copied to host memory on rank 0 ("to gathered framebuffer
-on host").
+on host").  The line's value is measured one frame at a time (a frame is complete before the next one starts, as a call
+of the reference's render() is).  The extra object "two_frames_in_flight" is the same K frames with the next frame's
+kernel queued on a second backend (stream) while the current one drains: a launch ends with a tail of a few very long
+paths, and the next frame's waves fill it.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -81,6 +84,8 @@ def parse():
                     help="local = VR_MODE_FAST_LOCAL: delta tracking over per-brick majorants (textbook regimes only; not the reference's estimator)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"], help="see the module docstring")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
+                    help="also measure the K frames with two in flight (extra object; auto: tracking workloads, not in rehearsal)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU work for the baseline sample")
     return ap.parse_args()
@@ -266,6 +271,53 @@ def main():
             weak = {"value": w["samples_per_step"] * a.steps / w["dt"] / 1e6, "unit": "Mpath-samples/s", "spp": spp * world,
                     "ms_per_step": w["dt"] / a.steps * 1e3,
                     "note": "same frame at spp x N samples per pixel, rows r::N per rank; measured after the timed steps"}
+    # the same K frames, two in flight: frame k renders on backend k % 2 while frame k - 1 is gathered and copied out
+    piped = None
+    want_pipe = a.pipeline == "on" or (a.pipeline == "auto" and not rehearsal and not mesh_scene)
+    if want_pipe:
+        be2 = Backend(local)
+        be2.set_mode({"exact": MODE_EXACT, "local": MODE_FAST_LOCAL}.get(a.mode, MODE_FAST))
+        be2.set_seed(scenes.SEED)
+        if mesh_scene:
+            be2.set_mesh(mesh)
+        else:
+            be2.generate_cloud(n, scenes.cloud_radius(n))
+            if mesh_tracker:
+                be2.set_density_map(*scenes.mesh_tracker_grid_map(n))
+                be2.set_mesh(mesh)
+        bes = [be, be2]
+        scheds = [sched, RowScheduler(H, W, dev, rank=rank, world=world)]
+        from volume_renderer_amd.scheduler import rows_of_rank
+        first, stride, count = rows_of_rank(rank, world, H)
+
+        def launch(k):
+            bes[k % 2].render_row_set_device(opts, integ_id, first, stride, count, scheds[k % 2].part.data_ptr())
+
+        def finish(k):
+            bes[k % 2].synchronize()
+            frame = scheds[k % 2].gather()
+            if rank == 0:
+                host_frame.copy_(frame)
+
+        for k in range(2):                      # warm-up: both backends' buffers exist
+            launch(k); finish(k)
+        fence()
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            launch(k)
+            if k > 0:
+                finish(k - 1)
+        finish(a.steps - 1)
+        fence()
+        tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        dtp = float(tp.item())
+        piped = {"value": W * H * int(opts.rayPerPixelCount) * a.steps / dtp / 1e6, "unit": "Mpath-samples/s", "ms_per_step": dtp / a.steps * 1e3,
+                 "steps": a.steps, "note": "the same K frames of the named workload, frame k + 1 queued on a second backend while frame k "
+                 "drains its tail and is gathered; every frame complete and on the host inside the timed region"}
+        be2.close()
+
     if rank == 0:
         dt, stats = main["dt"], main["stats"]
         lookups_all, kernel_ms_all, launches_all, loads_all = main["lookups"], main["kernel_ms"], main["launches"], main["loads"]
@@ -338,6 +390,8 @@ def main():
         }
         if weak is not None:
             out["weak_scaling"] = weak
+        if piped is not None:
+            out["two_frames_in_flight"] = piped
         want_cpu = a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and world == 1)
         if want_cpu:
             try:

@@ -60,6 +60,11 @@ class RowScheduler:
     def render(self, render_rows_fn):
         first, stride, count = rows_of_rank(self.rank, self.world, self.height)
         render_rows_fn(first, stride, count, self.part)
+        return self.gather()
+
+    def gather(self):
+        """The exchange alone: self.part (complete on this rank) -> the frame on rank 0.  Callers that keep several frames
+        in flight render into `part` asynchronously themselves and call this once the rows are there."""
         if self.world > 1:
             dist.all_gather_into_tensor(self.gathered, self.part)
             if self.rank == 0:
