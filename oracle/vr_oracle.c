@@ -196,7 +196,8 @@ void vro_minstd_canonical_double(uint32_t* state, double* out)
  *   shadow walk of that scatter event.  The Philox block (pixel, sample, tag, 0) is the state of a
  *   xoshiro128+ generator (Blackman & Vigna 2018, public domain: their generator for floats taken from
  *   the upper bits) from which the walk draws in order.
- *   An iteration that needs random numbers takes TWO words at its first draw: first = free path,
+ *   An iteration that needs random numbers takes TWO words at its first draw, both from ONE transition of the
+ *   generator (vro_xoshiro128p_next2: s0 + s3 and s1 + s2 of the same state): first = free path,
  *   second = collision type (camera walk) or roulette (shadow walk), both through their upper 24
  *   bits; the camera walk's Russian roulette at the loop top takes 16 bits from the low bytes of the
  *   same two words.  Iterations in empty space (sigma <= 0, no roulette) draw nothing, which lets the
@@ -244,6 +245,13 @@ uint32_t vro_xoshiro128p_next(uint32_t s[4])
     s[3] = (s[3] << 11) | (s[3] >> 21);
     return result;
 }
+/* Two words from ONE transition: the published output s0 + s3 and s1 + s2 of the same state (the two state words the
+ * published output does not read; over the period the four words are jointly uniform, so the sums are independent). */
+void vro_xoshiro128p_next2(uint32_t s[4], uint32_t out[2])
+{
+    out[1] = s[1] + s[2];
+    out[0] = vro_xoshiro128p_next(s);
+}
 /* the stream of walk `tag`: its state is the Philox block (pixel, sample, tag, 0) */
 static void rng_seed_stream(vro_rng* g)
 {
@@ -255,8 +263,7 @@ static void rng_seed_stream(vro_rng* g)
 static const uint32_t* rng_pair(vro_rng* g)
 {
     if (!g->pair_valid) {
-        g->pair[0] = vro_xoshiro128p_next(g->s);
-        g->pair[1] = vro_xoshiro128p_next(g->s);
+        vro_xoshiro128p_next2(g->s, g->pair);
         g->pair_valid = 1;
     }
     return g->pair;
@@ -307,8 +314,10 @@ static void rng_direction(vro_rng* g, float* xi1, float* xi2)
     g->tag += 1;
     g->step = 0;
     rng_seed_stream(g);
-    *xi1 = (unit24(vro_xoshiro128p_next(g->s)) * (0.9999f - 0.0f)) + 0.0f;
-    *xi2 = (unit24(vro_xoshiro128p_next(g->s)) * (0.9999f - 0.0f)) + 0.0f;
+    uint32_t w[2];
+    vro_xoshiro128p_next2(g->s, w);
+    *xi1 = (unit24(w[0]) * (0.9999f - 0.0f)) + 0.0f;
+    *xi2 = (unit24(w[1]) * (0.9999f - 0.0f)) + 0.0f;
 }
 /* the shadow walk of bounce b draws from stream (b | 0x80000000) */
 static void rng_push_shadow(vro_rng* g)

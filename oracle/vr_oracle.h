@@ -51,6 +51,7 @@ int  vro_get_math_mode(void);
 /* ---- function-level pieces (each cites the reference in vr_oracle.c) ---- */
 void     vro_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 uint32_t vro_xoshiro128p_next(uint32_t s[4]);   /* the per-walk stream generator (state = one Philox block) */
+void vro_xoshiro128p_next2(uint32_t s[4], uint32_t out[2]);   /* an iteration's two words: one transition, s0 + s3 and s1 + s2 */
 void     vro_mt19937_seed(uint32_t* state625, uint32_t seed);
 uint32_t vro_mt19937_next(uint32_t* state625);
 float    vro_reference_get_float(uint32_t* state625, float lo, float hi);

@@ -59,6 +59,8 @@ def lib():
     L.vro_philox4x32_10.argtypes = [_pu32, _pu32, _pu32]
     L.vro_xoshiro128p_next.argtypes = [_pu32]
     L.vro_xoshiro128p_next.restype = C.c_uint32
+    L.vro_xoshiro128p_next2.argtypes = [_pu32, _pu32]
+    L.vro_xoshiro128p_next2.restype = None
     L.vro_mt19937_seed.argtypes = [_pu32, C.c_uint32]
     L.vro_mt19937_next.argtypes = [_pu32]
     L.vro_mt19937_next.restype = C.c_uint32

@@ -49,6 +49,35 @@ def test_xoshiro128p_known_answers(oracle):
         t = (st[1] << 9) & M
         st[2] ^= st[0]; st[3] ^= st[1]; st[1] ^= st[2]; st[0] ^= st[3]; st[2] ^= t; st[3] = rotl(st[3], 11)
         assert oracle.vro_xoshiro128p_next(cs) == r and list(cs) == st
+    # an iteration's two words come from ONE transition: s0 + s3 (the published output) and s1 + s2 of the same state
+    out = (C.c_uint32 * 2)()
+    for _ in range(1000):
+        want = ((st[0] + st[3]) & M, (st[1] + st[2]) & M)
+        t = (st[1] << 9) & M
+        st[2] ^= st[0]; st[3] ^= st[1]; st[1] ^= st[2]; st[0] ^= st[3]; st[2] ^= t; st[3] = rotl(st[3], 11)
+        oracle.vro_xoshiro128p_next2(cs, out)
+        assert tuple(out) == want and list(cs) == st
+
+
+def test_the_two_words_of_a_transition_are_uncorrelated(oracle):
+    """s0 + s3 and s1 + s2 of one xoshiro128+ state, and each against the other's next value: sample correlation of
+    the 24-bit floats the walks make of them within 4 / sqrt(n), and the pair's joint 16x16 histogram flat (chi-square)."""
+    n = 200000
+    s = (C.c_uint32 * 4)(0x9E3779B9, 0x243F6A88, 0xB7E15162, 0x12345678)
+    out = (C.c_uint32 * 2)()
+    a = np.empty(n); b = np.empty(n)
+    for i in range(n):
+        oracle.vro_xoshiro128p_next2(s, out)
+        a[i] = (out[0] >> 8) / 16777216.0
+        b[i] = (out[1] >> 8) / 16777216.0
+    lim = 4.0 / np.sqrt(n)
+    assert abs(np.corrcoef(a, b)[0, 1]) < lim
+    assert abs(np.corrcoef(a[1:], b[:-1])[0, 1]) < lim and abs(np.corrcoef(a[:-1], b[1:])[0, 1]) < lim
+    assert abs(np.corrcoef(a[1:], a[:-1])[0, 1]) < lim and abs(np.corrcoef(b[1:], b[:-1])[0, 1]) < lim
+    h, _, _ = np.histogram2d(a, b, bins=16, range=[[0, 1], [0, 1]])
+    chi2 = float(((h - n / 256.0) ** 2 / (n / 256.0)).sum())
+    assert chi2 < 255 + 5 * np.sqrt(2 * 255), chi2          # 255 degrees of freedom
+    assert abs(a.mean() - 0.5) < lim and abs(b.mean() - 0.5) < lim
 
 
 def ulps(a, b):

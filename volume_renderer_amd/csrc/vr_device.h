@@ -86,7 +86,8 @@ struct Math<false> {
 //   is the 128-bit state of a xoshiro128+ generator (Blackman & Vigna 2018: their generator for
 //   floating-point numbers taken from the upper bits, which is the use here); the walk draws from it
 //   in order.  An iteration that needs random numbers (sigma > 0, or the camera walk's roulette) takes
-//   TWO words: first = free path, second = collision type (camera walk) or roulette (shadow walk), both
+//   TWO words from ONE transition of the generator (xoshiro128p_next2: s0 + s3 and s1 + s2 of the same state):
+//   first = free path, second = collision type (camera walk) or roulette (shadow walk), both
 //   through their upper 24 bits; the camera walk's roulette at the loop top uses 16 bits from the low
 //   bytes of the same two words.  Empty-space iterations draw nothing, so runs of them can be taken at
 //   once.  The stream of bounce b+1 starts with the two words of the direction sample that ends bounce b.
@@ -104,6 +105,23 @@ __device__ __forceinline__ uint32_t xoshiro128p_next(uint32_t& s0, uint32_t& s1,
     s1 = n1; s2 = n2;
     s3 = __builtin_amdgcn_alignbit(x3, x3, 32 - 11);                               // s3 = rotl(s3, 11)
     return result;
+}
+// Two words from ONE state transition: the published output s0 + s3 and, from the two state words it does not read,
+// s1 + s2.  Over the generator's period the four state words are jointly uniform, so the two sums are independent of
+// each other; an iteration of a walk needs exactly two words (free path, collision type), and the second transition it
+// used to pay for was seven of the ~40 VALU instructions of an iteration (+5 % on config 2: the step loop is bound by
+// its instruction count).  The oracle draws the same way (rng_pair in oracle/vr_oracle.c).
+__device__ __forceinline__ void xoshiro128p_next2(uint32_t& s0, uint32_t& s1, uint32_t& s2, uint32_t& s3, uint32_t& a, uint32_t& b)
+{
+    a = s0 + s3;
+    b = s1 + s2;
+    const uint32_t t = s1 << 9;
+    const uint32_t x3 = s3 ^ s1;
+    const uint32_t n1 = __builtin_amdgcn_bitop3_b32(s1, s2, s0, 0x96);
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32(s2, s0, t, 0x96);
+    s0 ^= x3;
+    s1 = n1; s2 = n2;
+    s3 = __builtin_amdgcn_alignbit(x3, x3, 32 - 11);
 }
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)

@@ -349,8 +349,11 @@ struct GeoVec<false> {
 // MESH: the walks are cut to the mesh's entry/exit interval (mesh_segment; event phases only).  Those kernels keep one
 // more dword of lane state in LDS (the medium's object) and get a wave less per SIMD: closest_hit needs registers
 // while the step loop's state is alive.
+#ifndef VR_MESH_WAVES_LESS
+#define VR_MESH_WAVES_LESS 1
+#endif
 template <int INTEG, bool EXACT, bool SKIP, bool IS, bool TEMP, bool SPAN, bool MESH = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VR_TRACK_WAVES(INTEG, EXACT, SPAN) - (MESH && !(EXACT) ? 1 : 0), VR_TRACK_WAVES(INTEG, EXACT, SPAN) - (MESH && !(EXACT) ? 1 : 0))))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VR_TRACK_WAVES(INTEG, EXACT, SPAN) - (MESH && !(EXACT) ? VR_MESH_WAVES_LESS : 0), VR_TRACK_WAVES(INTEG, EXACT, SPAN) - (MESH && !(EXACT) ? VR_MESH_WAVES_LESS : 0))))
 vr_track_kernel(const TrackParams p)
 {
     typedef Math<EXACT> M;
@@ -529,7 +532,8 @@ vr_track_kernel(const TrackParams p)
                 n_lookups += rng_step;
                 rng_ts += 1u << 20; rng_step = 0;
                 seed_stream();
-                const uint32_t h0 = xoshiro128p_next(xs0, xs1, xs2, xs3), h1 = xoshiro128p_next(xs0, xs1, xs2, xs3);
+                uint32_t h0, h1;
+                xoshiro128p_next2(xs0, xs1, xs2, xs3, h0, h1);
                 const float xi1 = in_range(h0, 0.0f, 0.9999f);
                 const float xi2 = in_range(h1, 0.0f, 0.9999f);
                 const f3 scattered = hg_sample<EXACT>(c->g, wdir, xi1, xi2);              // :156-159
@@ -709,7 +713,8 @@ vr_track_kernel(const TrackParams p)
                 const bool roulette = INTEG == INTEG_RATIO && !in_shadow && T < 0.05f;
                 if (!roulette && !(sigma > 0.0f)) { empty = true; continue; }
                 // the iteration's two words
-                const uint32_t w_path = xoshiro128p_next(xs0, xs1, xs2, xs3), w_event = xoshiro128p_next(xs0, xs1, xs2, xs3);
+                uint32_t w_path, w_event;
+                xoshiro128p_next2(xs0, xs1, xs2, xs3, w_path, w_event);
                 if (roulette) {
                     // Russian roulette on the camera walk     IntegratorRatioTracking.cpp:57-69
                     // (a path it ends does not count the lookup above, as in the reference)
@@ -970,7 +975,8 @@ vr_delta_dda_kernel(const DdaParams p)
                 depth_remaining--;
                 rng_ts += 1u << 20;
                 seed_stream();
-                const uint32_t h0 = xoshiro128p_next(xs0, xs1, xs2, xs3), h1 = xoshiro128p_next(xs0, xs1, xs2, xs3);
+                uint32_t h0, h1;
+                xoshiro128p_next2(xs0, xs1, xs2, xs3, h0, h1);
                 const f3 scattered = hg_sample<false>(c->g, wdir, in_range(h0, 0.0f, 0.9999f), in_range(h1, 0.0f, 0.9999f));   // :124-127
                 const f3 point = ray_at(eye, dir, t);                                         // :130
                 wdir = scattered;                                                             // :146
@@ -1076,8 +1082,8 @@ vr_delta_dda_kernel(const DdaParams p)
                 float t_next = __builtin_huge_valf();
                 uint32_t w_event = 0;
                 if (mu > 0.0f) {
-                    const uint32_t w_path = xoshiro128p_next(xs0, xs1, xs2, xs3);
-                    w_event = xoshiro128p_next(xs0, xs1, xs2, xs3);
+                    uint32_t w_path;
+                    xoshiro128p_next2(xs0, xs1, xs2, xs3, w_path, w_event);
                     const float u = fmaf((float)(w_path >> 8), (1.0f - 0.00001f) / 16777216.0f, 0.00001f);   // getFloat(0.00001, 1), :63
                     t_next = fmaf(__builtin_amdgcn_logf(u), -0.6931471805599453f * __builtin_amdgcn_rcpf(mu), t);
                 }
