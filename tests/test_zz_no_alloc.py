@@ -12,7 +12,7 @@ import pytest
 
 import oracle_lib as ol
 import scenes
-from volume_renderer_amd import MODE_EXACT_SKIP, MODE_FAST, Backend, BackendError, Grid
+from volume_renderer_amd import MODE_EXACT_SKIP, MODE_FAST, MODE_FAST_LOCAL, Backend, BackendError, Grid
 
 pytestmark = pytest.mark.gpu
 
@@ -70,6 +70,20 @@ def test_noalloc_matches_allocating_entry_point_two_calls_in_a_row(backend, clou
         (a, ast), (b, bst) = both(backend, small, integ, row_first=1, row_stride=2, rows=14)
         assert bitexact(a, b) and ast == bst, (integ, "small")
         assert ast["path_samples"] == 37 * 14 * 4
+    # the kernels added in round 2: the local-majorant delta tracker and the mesh-bounded trackers
+    backend.set_mode(MODE_FAST_LOCAL)
+    (a, ast), (b, bst) = both(backend, scenes.options_cloud(DELTA, 64, 83, 61, 16, regime="textbook"), DELTA)
+    assert bitexact(a, b) and ast == bst and ast["path_samples"] == 83 * 61 * 16
+    (a, ast), (b, bst) = both(backend, scenes.options_cloud(DELTA, 64, 37, 29, 4, regime="textbook"), DELTA, row_first=1, row_stride=2, rows=14)
+    assert bitexact(a, b) and ast == bst
+    backend.set_density_map(*scenes.mesh_tracker_grid_map(64))
+    for integ in (8, 9):                                             # meshRatioTracking, meshDeltaTracking
+        backend.set_mode(MODE_EXACT_SKIP)
+        (a, ast), (b, bst) = both(backend, scenes.options_mesh_tracker(integ, 64, 70, 50, 4), integ)
+        assert bitexact(a, b) and ast == bst and ast["ray_queries"] >= 70 * 50 * 4, (integ, "big")
+        (a, ast), (b, bst) = both(backend, scenes.options_mesh_tracker(integ, 64, 31, 23, 1), integ)
+        assert bitexact(a, b) and ast == bst, (integ, "small")
+    backend.set_density(cloud64)
     for integ in (NEE, IMPROVED):
         backend.set_mode(MODE_EXACT_SKIP)
         (a, ast), (b, bst) = both(backend, scenes.options_marcher(90, 70, 4), integ)
