@@ -810,7 +810,10 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 dp.major = b->d_major + b->major_off[level]; dp.cell_log = 3 + level;
                 for (int a = 0; a < 3; ++a) dp.nc[a] = b->major_nc[level][a];
                 dp.sigma_a = o->sigma_a; dp.sigma_s = o->sigma_s; dp.light_mult = o->lightRayDensityMultiplier;
-                dp.round_max = tuned(b->tune_round_max, 64); dp.round_events = tuned(b->tune_round_events, 16);
+                // a round ends when 44 of the 64 lanes wait for the event code: the phases (path set-up, Philox, direction sample) cost far more
+                // than the DDA steps, so they run as full as they can (swept: 2001 / 2720 / 3218 / 3574 / 3785 / 3765 / 3631 M samples/s for
+                // 8 / 16 / 24 / 32 / 44 / 52 / 58 on config 3 textbook; the global-majorant kernels peak at 24)
+                dp.round_max = tuned(b->tune_round_max, 64); dp.round_events = tuned(b->tune_round_events, 44);
                 void (*dk)(const DdaParams) = b->has_temperature ? vr_delta_dda_kernel<true> : vr_delta_dda_kernel<false>;
                 int per_cu = 8;
                 rc = launch_cap(b, dk, dp, per_cu);
@@ -844,7 +847,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             // event phase (measured per regime: sub-voxel steps have long trips and rare events, voxel-sized
             // steps one iteration per trip and an event every few iterations)
             p.round_max = tuned(b->tune_round_max, span ? VR_ROUND_MAX : 2 * VR_ROUND_MAX);
-            p.round_events = tuned(b->tune_round_events, span ? (ratio ? 16 : VR_ROUND_EVENTS) : 2 * VR_ROUND_EVENTS);
+            p.round_events = tuned(b->tune_round_events, span ? VR_ROUND_EVENTS : 2 * VR_ROUND_EVENTS);   // (the ratio tracker took 16 while a trip drew from the generator twice per iteration; 12 since: +1.5 %)
             void (*kern)(const TrackParams);
             // empty-space runs read the skip grid, whose empty voxels only keep the sign of sigma for
             // multipliers >= 0 (the shadow multiplier is only read by the ratio tracker)
