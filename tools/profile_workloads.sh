@@ -13,7 +13,7 @@ for e in "config3_delta_1080p_256spp_cloud512 fast" "config3_textbook fast" "con
          "perlin_marcher_sphere_1080p fast"; do
   set -- $e
   w=$1; m=$2; tag=${w}_${m}
-  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$tag -- python3 $R/bench.py --workload $w --mode $m --steps 2 --warmup 1 --cpu-seconds 8 ${3:+--spp $3} > $O/$tag.log 2>&1 || { tail -5 $O/$tag.log; exit 1; }
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$tag -- python3 $R/bench.py --workload $w --mode $m --steps 2 --warmup 1 --cpu-seconds 8 --pipeline off ${3:+--spp $3} > $O/$tag.log 2>&1 || { tail -5 $O/$tag.log; exit 1; }
   f=$(find $O/$tag -name "*kernel_stats.csv" | head -1)
   cp "$f" $O/${tag}_kernel_stats.csv
   grep '^{"metric"' $O/$tag.log | tail -1 > $O/${tag}_bench.json

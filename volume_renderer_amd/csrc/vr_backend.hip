@@ -846,8 +846,12 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             // a round of the step loop ends after round_max trips or when round_events lanes wait for the
             // event phase (measured per regime: sub-voxel steps have long trips and rare events, voxel-sized
             // steps one iteration per trip and an event every few iterations)
-            p.round_max = tuned(b->tune_round_max, span ? VR_ROUND_MAX : 2 * VR_ROUND_MAX);
-            p.round_events = tuned(b->tune_round_events, span ? VR_ROUND_EVENTS : 2 * VR_ROUND_EVENTS);   // (the ratio tracker took 16 while a trip drew from the generator twice per iteration; 12 since: +1.5 %)
+            // The mesh-bounded kernels' event phases hold the closest-hit queries (a BVH traversal per new ray, 1 200-3 600
+            // instructions for the few lanes that wait), so their rounds run as long and as full as they can: 48 waiting lanes
+            // and up to 96 trips (swept on config 5's tracker leg: ratio 129 -> 181 M samples/s, delta 450 -> 828 shipped,
+            // 519 -> 1 010 textbook against the limits of the plain kernels).
+            p.round_max = tuned(b->tune_round_max, (span && !mesh_bound) ? VR_ROUND_MAX : 2 * VR_ROUND_MAX);
+            p.round_events = tuned(b->tune_round_events, mesh_bound ? 4 * VR_ROUND_EVENTS : (span ? VR_ROUND_EVENTS : 2 * VR_ROUND_EVENTS));   // (the ratio tracker took 16 while a trip drew from the generator twice per iteration; 12 since: +1.5 %)
             void (*kern)(const TrackParams);
             // empty-space runs read the skip grid, whose empty voxels only keep the sign of sigma for
             // multipliers >= 0 (the shadow multiplier is only read by the ratio tracker)
