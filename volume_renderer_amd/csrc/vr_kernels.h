@@ -364,7 +364,7 @@ vr_track_kernel(const TrackParams p)
     const float fast_c_ln = -0.6931471805599453f * p.step_mult;                 // len = log2(u) * fast_c_ln / denominator
     const float fast_c_cam = fast_c_ln / p.sigma_maj;
     const float fast_sig_t = p.sigma_a + p.sigma_s;                             // mu_t = sigma * fast_sig_t
-    const float fast_sig_t2 = -(p.sigma_a + p.sigma_s) * 1.4426950408889634f;   // exp(-len mu_t) = exp2(len * sigma * fast_sig_t2)
+    const float fast_sig_t2 = (p.sigma_a + p.sigma_s) * 1.4426950408889634f;    // optical depth in bits = len * sigma * fast_sig_t2
     const float fast_pa24 = p.sigma_a / p.sigma_maj * 16777216.0f, fast_ps24 = p.sigma_s / p.sigma_maj * 16777216.0f;
 
     // ---- per-lane path state (HandleIntersectionData, BaseIntegrator.h:21-50) ----
@@ -382,8 +382,15 @@ vr_track_kernel(const TrackParams p)
     float    t = 0, t1 = 0;             // tFar, iRay.t1()
     LdsF3    wdir{cold_lane};           // data->rayDirection
     LdsF3    radiance{cold_lane + 3 * 256};   // data->radiance / result
-    // data->transmission, shadow-walk transmission
-    float    T = 1.0f, Tsh = 1.0f;
+    // data->transmission, shadow-walk transmission.  EXACT keeps them as the reference does.  FAST keeps -log2 of them
+    // (optical depth in bits): attenuating by exp(-len mu_t) is then ONE fma in the step loop instead of a multiply,
+    // a v_exp_f32 (quarter rate) and another multiply, the roulette's "T < 0.05" is "depth > log2(20)", its "T /= 0.25"
+    // is "depth -= 2" (exact), a dead walk is +inf, and the value itself (trans()) is only needed in the event phase.
+    constexpr float T_ONE = EXACT ? 1.0f : 0.0f;
+    constexpr float DEPTH_ROULETTE = 4.321928094887362f;   // -log2(0.05)
+    float    T = T_ONE, Tsh = T_ONE;
+    auto trans = [](float x) -> float { return EXACT ? x : __builtin_amdgcn_exp2f(-x); };
+    auto faint = [](float x) -> bool { return EXACT ? x < 0.05f : x > DEPTH_ROULETTE; };   // the roulette's condition
     // iRay.t0() of the camera ray is read when its shadow walk starts, which is where Tsh is first written, and
     // written again when the next camera ray starts, after Tsh was last read: the two share a register
     float&   t0 = Tsh;
@@ -473,11 +480,11 @@ vr_track_kernel(const TrackParams p)
                 if (st == ST_ESCAPED) {
                     // survivor: radiance + background * transmission            IntegratorRatioTracking.cpp:208 (delta :175)
                     const f3 bg = mk3(c->background[0], c->background[1], c->background[2]);
-                    radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, T) : bg);
+                    radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, trans(T)) : bg);
                 } else {
                     const f3 medium = mk3(c->medium[0], c->medium[1], c->medium[2]);
                     if (INTEG == INTEG_RATIO) {                                   // :127-131
-                        radiance = add3(radiance, scale3(medium, T));
+                        radiance = add3(radiance, scale3(medium, trans(T)));
                     } else {                                                      // delta :101-113
                         if (TEMP)
                             radiance = add3(radiance, scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), scatter_len));
@@ -505,10 +512,10 @@ vr_track_kernel(const TrackParams p)
                     seg = mesh_clip(c->mesh, index_to_world(c->mat, c->vec, so), mat_mult(c->mat, light), 1.0f, medium, m2, c0, c1, seg_empty, n_queries);
                 }
                 if (!in_box || (MESH && (seg == SEG_BLACK || seg_empty))) {       // :229-232
-                    Tsh = (MESH && in_box && seg == SEG_BLACK) ? 0.0f : 1.0f;     // an opaque surface between the point and the light
+                    Tsh = (MESH && in_box && seg == SEG_BLACK) ? (EXACT ? 0.0f : __builtin_inff()) : T_ONE;     // an opaque surface between the point and the light
                     st = ST_SHADOW_DONE;
                 } else {
-                    shadow = true; Tsh = 1.0f; st = ST_WALK;
+                    shadow = true; Tsh = T_ONE; st = ST_WALK;
                     seed_stream();
                     set_ray(so, light, c0, c1);
                 }
@@ -523,7 +530,7 @@ vr_track_kernel(const TrackParams p)
                     const f3 light = mk3(c->light[0], c->light[1], c->light[2]);
                     const float cos_theta = dot3(wdir, light);                            // :144
                     const float hg = hg_phase<EXACT>(c->g, cos_theta);                    // :145
-                    f3 nee = scale3(mk3(c->light_color[0], c->light_color[1], c->light_color[2]), T * Tsh); // :147-152
+                    f3 nee = scale3(mk3(c->light_color[0], c->light_color[1], c->light_color[2]), EXACT ? T * Tsh : trans(T + Tsh)); // :147-152
                     nee = scale3(nee, scatter_len);
                     nee = scale3(nee, hg);
                     radiance = add3(radiance, nee);
@@ -566,7 +573,7 @@ vr_track_kernel(const TrackParams p)
                     // `while (... && depthRemaining > 0)`: out of scatter budget, the walk ends as
                     // escaped                                                            :55, :208 (delta :54, :175)
                     const f3 bg = mk3(c->background[0], c->background[1], c->background[2]);
-                    radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, T) : bg);
+                    radiance = add3(radiance, INTEG == INTEG_RATIO ? scale3(bg, trans(T)) : bg);
                     st = ST_FINISHED;
                 } else {
                     t0 = c0; st = ST_WALK;                                                // :179, :189
@@ -679,7 +686,7 @@ vr_track_kernel(const TrackParams p)
                         st = ST_WALK; shadow = false;
                         t0 = c0;
                         radiance = mk3(0, 0, 0);
-                        T = 1.0f;
+                        T = T_ONE;
                         depth_remaining = (int)c->max_depth;
                         rng_pixel = (cj << 16) | ci; rng_ts = s; rng_step = 0;
                         seed_stream();
@@ -710,7 +717,7 @@ vr_track_kernel(const TrackParams p)
                 const float mult = in_shadow ? p.shadow_mult : p.light_mult;
                 const float sigma = mult * cur_val;
 
-                const bool roulette = INTEG == INTEG_RATIO && !in_shadow && T < 0.05f;
+                const bool roulette = INTEG == INTEG_RATIO && !in_shadow && faint(T);
                 if (!roulette && !(sigma > 0.0f)) { empty = true; continue; }
                 // the iteration's two words
                 uint32_t w_path, w_event;
@@ -719,9 +726,14 @@ vr_track_kernel(const TrackParams p)
                     // Russian roulette on the camera walk     IntegratorRatioTracking.cpp:57-69
                     // (a path it ends does not count the lookup above, as in the reference)
                     const float q = 0.75f;
-                    if (roulette16(w_path, w_event) < q) T = 0.0f;
-                    else T /= 1.0f - q;
-                    if (T <= 0.0f) { st = ST_FINISHED; continue; }
+                    if (EXACT) {
+                        if (roulette16(w_path, w_event) < q) T = 0.0f;
+                        else T /= 1.0f - q;
+                        if (T <= 0.0f) { st = ST_FINISHED; continue; }
+                    } else {
+                        if (roulette16(w_path, w_event) < q) { st = ST_FINISHED; continue; }
+                        T -= 2.0f;
+                    }
                     if (!(sigma > 0.0f)) { empty = true; continue; }
                 }
 
@@ -762,17 +774,26 @@ vr_track_kernel(const TrackParams p)
                     // rayPDF *= mu_t * sampleAttenuation (a double there)                 :106 (delta :91)
                     if (IS && !in_shadow) pdf = (float)((double)pdf * ((double)mu_t * (double)att));
                 } else {
-                    if (INTEG == INTEG_RATIO || IS) att = __builtin_amdgcn_exp2f(len * (sigma * fast_sig_t2));
-                    if (IS && !in_shadow) pdf *= (sigma * fast_sig_t) * att;
+                    // FAST: `att` is the step's optical depth in bits, len * mu_t * log2(e)
+                    if (INTEG == INTEG_RATIO) att = len * (sigma * fast_sig_t2);
+                    if (IS && !in_shadow) pdf *= (sigma * fast_sig_t) * __builtin_amdgcn_exp2f(-(len * (sigma * fast_sig_t2)));
                 }
                 if (in_shadow) {
-                    Tsh *= att;
-                    if (Tsh < 0.05f) {                                                        // :272-279
-                        const float q = 0.75f;
-                        if (in_range(w_event, 0.0f, 1.0f) < q) Tsh = 0.0f;
-                        else Tsh /= 1.0f - q;
+                    const float q = 0.75f;
+                    if (EXACT) {
+                        Tsh *= att;
+                        if (Tsh < 0.05f) {                                                    // :272-279
+                            if (in_range(w_event, 0.0f, 1.0f) < q) Tsh = 0.0f;
+                            else Tsh /= 1.0f - q;
+                        }
+                        if (Tsh <= 0.0f) st = ST_SHADOW_DONE;                                 // :281
+                    } else {
+                        Tsh += att;
+                        if (Tsh > DEPTH_ROULETTE) {
+                            if (in_range(w_event, 0.0f, 1.0f) < q) { Tsh = __builtin_inff(); st = ST_SHADOW_DONE; }
+                            else Tsh -= 2.0f;
+                        }
                     }
-                    if (Tsh <= 0.0f) st = ST_SHADOW_DONE;                                     // :281
                 } else {
                     // collision type: null / absorption / scattering                         :98-100, :108
                     bool is_null, is_absorb;
@@ -793,14 +814,14 @@ vr_track_kernel(const TrackParams p)
                         is_null = sample < pNull;
                         is_absorb = sample < pNull + pA;
                     }
-                    if (INTEG == INTEG_RATIO) T = T * att;
+                    if (INTEG == INTEG_RATIO) T = EXACT ? T * att : T + att;
                     if (INTEG == INTEG_RATIO && TEMP) {                          // :110-122
                         const TrackCold* c = opaque(p.cold);
                         const float emission = grid_value_nocache(c->temperature, ray_at(eye, dir, t));
                         n_lookups++;
                         n_loads++;
                         if (emission > 0.0f) {
-                            f3 e = scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), T * (sigma * p.sigma_a));
+                            f3 e = scale3(mk3(c->emission[0], c->emission[1], c->emission[2]), trans(T) * (sigma * p.sigma_a));
                             e = scale3(e, emission);
                             e = scale3(e, len);
                             radiance = add3(radiance, e);
@@ -817,7 +838,7 @@ vr_track_kernel(const TrackParams p)
                         // scattering                                                        :133-191 (delta :115-158)
                         depth_remaining--;                                                    // :136 (the `< 0` test never fires)
                         n_scatter++;
-                        if (INTEG == INTEG_DELTA || T > 0.0f) {                               // :141
+                        if (INTEG == INTEG_DELTA || !EXACT || T > 0.0f) {                     // :141 (FAST: a walk the roulette ended never gets here)
                             scatter_p = ray_at(eye, dir, t);                                  // :162 (delta :130)
                             scatter_len = len;
                             st = INTEG == INTEG_DELTA ? ST_SHADOW_DONE : ST_SCATTER;
@@ -832,7 +853,7 @@ vr_track_kernel(const TrackParams p)
                 const float len = in_shadow ? tmin * 100 : tmin * 10;                         // :252 / :85
                 uint32_t    krun = 1;
                 // a run must not span iterations that would play roulette (T < 0.05 on the camera walk)
-                const bool can_run = INTEG == INTEG_DELTA || in_shadow || !(T < 0.05f);
+                const bool can_run = INTEG == INTEG_DELTA || in_shadow || !faint(T);
                 if (SKIP && cur_off != 0xffffffffu && can_run) {
                     // the skip grid holds -(r + 1) where every voxel of the cube of radius r is empty
                     float t_safe = t_span;
@@ -848,7 +869,11 @@ vr_track_kernel(const TrackParams p)
             if (st == ST_WALK) prefetch();
             // leave for the event phase once enough lanes wait for it, or none walks any more
             const int n_walk = __popcll(__ballot(st == ST_WALK));
+#ifdef VR_DRAIN_EXP
+            if (chunk_dry) { w_trips++; w_trip_lanes += (unsigned)n_walk; }   // experiment: the divergence counters see the drain only
+#else
             w_trips++; w_trip_lanes += (unsigned)n_walk;
+#endif
             const int n_event = __popcll(__ballot(st >= ST_SCATTER));
             if (n_event >= p.round_events || n_walk == 0) break;
         }
