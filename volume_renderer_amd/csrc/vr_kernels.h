@@ -871,6 +871,14 @@ vr_track_kernel(const TrackParams p)
             const int n_walk = __popcll(__ballot(st == ST_WALK));
 #ifdef VR_DRAIN_EXP
             if (chunk_dry) { w_trips++; w_trip_lanes += (unsigned)n_walk; }   // experiment: the divergence counters see the drain only
+#elif defined(VR_EMPTY_EXP)
+#ifndef VR_EMPTY_EXP_D
+#define VR_EMPTY_EXP_D 0
+#endif
+            // experiment: trips that ran the empty-space block, and the lanes in it whose voxel has a distance of at least VR_EMPTY_EXP_D
+            if (__any(empty)) { w_trips++; w_trip_lanes += (unsigned)__popcll(__ballot(empty && !(cur_val > -(float)VR_EMPTY_EXP_D))); }
+#elif defined(VR_PARK_EXP)
+            if (__any(parked)) { w_trips++; w_trip_lanes += (unsigned)__popcll(__ballot(parked)); }  // experiment: trips with lanes that left their voxel early
 #else
             w_trips++; w_trip_lanes += (unsigned)n_walk;
 #endif
