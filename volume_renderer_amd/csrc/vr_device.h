@@ -216,29 +216,27 @@ __device__ __forceinline__ uint32_t brick_offset(const GridDev& g, uint32_t i, u
 // ordinary float addition that may leave it.  t advances exactly as that many sequential float
 // additions would:  inside one binade [2^e, 2^(e+1)) a float is m * 2^(e-23) with integer m, and
 // fl(t + step) = t + q * 2^(e-23) with q = step / 2^(e-23) rounded to nearest (ties are not
-// handled here: they fall back to a single step), so k additions add k*q to the integer bit
-// pattern of t.  The box is shrunk by `slack` on every side, which covers the rounding of
+// handled here: they fall back to a single step), so k additions add k * q * 2^(e-23), exactly.  The box is shrunk by `slack` on every side, which covers the rounding of
 // fmaf(t, dir, eye) and of the exit-distance estimate; estimates only ever make the run shorter.
 __device__ __forceinline__ uint32_t empty_run(float& t, float t_safe, float step)
 {
-    const uint32_t tb = __float_as_uint(t);
-    const uint32_t et = tb >> 23;                                  // t > 0: sign bit clear
+    // q * ulp(t), read off the first step itself: fl(t + step) - t is exact while the sum stays in t's binade (and
+    // where it does not, the limit below leaves nothing to batch)
+    const float    qu = (t + step) - t;
+    const uint32_t tb = __float_as_uint(t);                        // t > 0: sign bit clear
+    const float    half_ulp = __uint_as_float(tb & 0x7f800000u) * 5.9604644775390625e-08f;   // 2^(e-24); 0 for a denormal t: no batch
+    // a tie (step / ulp(t) = n + 1/2) rounds to even and alternates between n and n + 1: not batched.  The difference
+    // is exact (qu and step are within a factor of two of each other once step >= ulp / 2)
+    const bool     regular = qu > 0.0f && fabsf(qu - step) != half_ulp;
+    // the batched steps stay at or below the last float of t's binade, so every one of them adds exactly qu, and at
+    // or below t_safe
+    const float t_last = __uint_as_float(tb | 0x7fffffu);
+    const float t_lim = t_safe < t_last ? t_safe : t_last;
+    const float kf = floorf((t_lim - t) * __builtin_amdgcn_rcpf(qu) * 0.999999f) - 1.0f;
     uint32_t k = 0;
-    if (t_safe > t && et >= 24u && et < 254u) {
-        const float x = step * __uint_as_float((277u - et) << 23); // step / ulp(t), exact
-        const float qf = rintf(x);                                 // q (a tie is excluded below)
-        if (x >= 1.0f && x < 4194304.0f && fabsf(x - qf) != 0.5f) {
-            const float qu = qf * __uint_as_float((et - 23u) << 23);   // q * ulp(t), exact
-            // the batched steps stay at or below the last float of t's binade, so the bit pattern
-            // never carries into the exponent, and at or below t_safe
-            const float t_last = __uint_as_float(tb | 0x7fffffu);
-            const float t_lim = t_safe < t_last ? t_safe : t_last;
-            const float kf = floorf((t_lim - t) * __builtin_amdgcn_rcpf(qu) * 0.999999f) - 1.0f;
-            if (kf >= 1.0f) {
-                k = (uint32_t)kf;
-                t = __uint_as_float(tb + k * (uint32_t)qf);
-            }
-        }
+    if (regular && kf >= 1.0f) {
+        k = (uint32_t)kf;
+        t = fmaf(kf, qu, t);   // exact: k q < 2^23 and the sum does not leave the binade
     }
     // the k steps above all START and END inside the box; one more ordinary step starts inside it
     // (same sigma <= 0) and may end anywhere: the caller looks the new position up as usual

@@ -445,13 +445,13 @@ vr_track_kernel(const TrackParams p)
         }
         cur_val = n_val; cur_off = n_off; t_span = n_span;
     };
-    // same bound for the cube of `radius` voxels around the voxel of iRay(t)
+    // a lower bound of the same for the cube of `radius` voxels around the current voxel.  Per axis the cube's far face
+    // lies radius * |1 / dir| beyond the voxel's, so the ray stays inside until at least t_span + radius * min |1 / dir|
+    // (the exact minimum over the axes ends at most one voxel crossing later; it cost the block 20 instructions and
+    // five more LDS reads on every trip: config 2 A/B in DESIGN.md 6b).  A shorter run never changes a result.
     auto cube_span = [&](float radius) -> float {
-        const f3 d_ = dir, so_ = span_off, in_ = inv;
-        const f3 q = ray_at(eye, d_, t);
-        const float cx = floorf(q.x) + copysignf(radius, d_.x), cy = floorf(q.y) + copysignf(radius, d_.y),
-                    cz = floorf(q.z) + copysignf(radius, d_.z);
-        return fminf(fminf((cx + so_.x) * in_.x, (cy + so_.y) * in_.y), (cz + so_.z) * in_.z);
+        const f3 in_ = inv;
+        return fmaf(radius, fminf(fminf(fabsf(in_.x), fabsf(in_.y)), fabsf(in_.z)), t_span);
     };
     // a walk's stream: the Philox block of (pixel, sample, tag) is the generator's state
     auto seed_stream = [&]() {
