@@ -1004,10 +1004,11 @@ vr_delta_dda_kernel(const DdaParams p)
             if (st == DD_SCATTER) {
                 // IntegratorDeltaTracking.cpp:115-158: a new direction from the phase function, the walk goes on from
                 // the collision point
+                // (one stream per PATH here: the walk after a scatter goes on drawing from the generator the refill
+                // seeded.  The other kernels key a stream per bounce so that the oracle can restate them walk by walk;
+                // this estimator has no oracle to follow, and Philox at every scatter was a tenth of its event phases.)
                 n_scatter++;
                 depth_remaining--;
-                rng_ts += 1u << 20;
-                seed_stream();
                 uint32_t h0, h1;
                 xoshiro128p_next2(xs0, xs1, xs2, xs3, h0, h1);
                 const f3 scattered = hg_sample<false>(c->g, wdir, in_range(h0, 0.0f, 0.9999f), in_range(h1, 0.0f, 0.9999f));   // :124-127
