@@ -377,7 +377,8 @@ vr_track_kernel(const TrackParams p)
     typename Geo::type eye = Geo::make(cold_lane + 14 * 256), dir = Geo::make(cold_lane + 17 * 256);   // current index-space ray (camera walk or shadow walk)
     // voxel-span / empty-run estimates only: 1/dir (NaN where dir == 0: fminf then ignores that axis)
     // and, per axis, (dir > 0 ? 1 - slack : slack) - eye, so that the ray leaves the shrunk voxel
-    // whose corner is f at t = (f + span_off) * inv
+    // whose corner is f at t = (f + offset) * inv = fma(f, inv, span_off) with span_off = offset * inv, which is what
+    // is kept (its rounding moves the face by |eye| * 1e-7 voxels, far inside the slack)
     typename Geo::type inv = Geo::make(cold_lane + 20 * 256), span_off = Geo::make(cold_lane + 23 * 256);
     float    t = 0, t1 = 0;             // tFar, iRay.t1()
     LdsF3    wdir{cold_lane};           // data->rayDirection
@@ -440,7 +441,7 @@ vr_track_kernel(const TrackParams p)
                 // ray parameter at which the walk leaves the voxel shrunk by `slack` on every side (see empty_run)
             {
                 const f3 so_ = span_off, in_ = inv;
-                n_span = fminf(fminf((fx + so_.x) * in_.x, (fy + so_.y) * in_.y), (fz + so_.z) * in_.z);
+                n_span = fminf(fminf(fmaf(fx, in_.x, so_.x), fmaf(fy, in_.y, so_.y)), fmaf(fz, in_.z, so_.z));
             }
         }
         cur_val = n_val; cur_off = n_off; t_span = n_span;
@@ -463,8 +464,11 @@ vr_track_kernel(const TrackParams p)
         const float slack = 0.01f, nan = __builtin_nanf("");
         inv = mk3(d.x != 0 ? __builtin_amdgcn_rcpf(d.x) : nan, d.y != 0 ? __builtin_amdgcn_rcpf(d.y) : nan,
                   d.z != 0 ? __builtin_amdgcn_rcpf(d.z) : nan);
-        span_off = mk3((d.x > 0 ? 1.0f - slack : slack) - e.x, (d.y > 0 ? 1.0f - slack : slack) - e.y,
-                       (d.z > 0 ? 1.0f - slack : slack) - e.z);
+        {
+            const f3 in_ = inv;
+            span_off = mk3(((d.x > 0 ? 1.0f - slack : slack) - e.x) * in_.x, ((d.y > 0 ? 1.0f - slack : slack) - e.y) * in_.y,
+                           ((d.z > 0 ? 1.0f - slack : slack) - e.z) * in_.z);
+        }
         t_span = a;   // force a lookup
         cur_off = 0xffffffffu;
         prefetch();
