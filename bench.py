@@ -332,8 +332,8 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                pmc = json.load(f).get(a.workload, {})
-        use_pmc = world == 1 and not a.spp and a.mode == "fast"      # the committed counters are per launch of THIS frame
+                pmc = json.load(f).get(a.workload if a.mode == "fast" else f"{a.workload}:{a.mode}", {})
+        use_pmc = world == 1 and not a.spp and bool(pmc)             # the committed counters are per launch of THIS frame in THIS mode
         traffic = pmc.get("hbm_bytes_per_launch") if use_pmc else None
         kernel_name = {0: "vr_march_kernel", 1: "vr_march_kernel", 6: "vr_march_kernel", 7: "vr_march_kernel", 4: "vr_gridmarch_kernel",
                        5: "vr_gridmarch_kernel"}.get(integ_id, "vr_track_kernel")

@@ -121,6 +121,38 @@ def test_skip_grid_runs_do_not_change_image_or_counts(backend, oracle, integ, mu
 
 
 @pytest.mark.parametrize("integ", [RATIO, DELTA])
+def test_empty_runs_where_the_step_is_a_rounding_tie(backend, oracle, integ):
+    """empty_run batches k additions of the empty-space step as k * q * ulp(t), q = step / ulp(t) rounded.  Where
+    step / ulp(t) is exactly n + 1/2 the additions round to even and alternate between n and n + 1, so such a binade
+    must fall back to single steps.  stepSizeMin = 0.0010000229 makes the camera walk's empty step (10 x) exactly
+    2621.5 ulp for t in [32, 64) — a tie there, regular in the binades on either side, and the walks of this scene
+    cross all three: image and counts must stay bit-identical to the single-stepping oracle."""
+    tmin = float(np.float32(0.0010000228649005294))
+    step = np.float32(np.float32(tmin) * np.float32(10))
+    assert float(step) * 2.0**18 == 2621.5                                # the tie, exactly
+    t0 = np.nextafter(np.float32(40.0), np.float32(41.0))                 # odd mantissa: ties-to-even adds 2621 ulp, then 2622
+    t2 = np.float32(t0 + step) + step
+    assert int(t2.view(np.uint32)) - int(t0.view(np.uint32)) == 5243      # not 2 * rint(2621.5) = 5244
+    g = _holes_grid()
+    o = scenes.options_cloud(integ, 64, 16, 12, 2, regime="shipped")
+    o.cameraPosition[2] = 60.0
+    o.stepSizeMin = tmin
+    o.stepSizeMax = 4.0
+    sc, _keep = ol.make_scene(density=g)
+    want, wst = oracle_image(oracle, sc, o, integ)
+    backend.set_density(g)
+    backend.set_seed(scenes.SEED)
+    for mode in (MODE_EXACT, MODE_EXACT_SKIP):
+        backend.set_mode(mode)
+        got = backend.render(o, integ)
+        st = backend.last_stats()
+        assert bitexact(got, want), f"mode {mode}: {np.count_nonzero(got.view(np.uint32) != want.view(np.uint32))} of {got.size} channels differ"
+        for k in ("path_samples", "density_lookups", "scatter_events", "shadow_rays"):
+            assert st[k] == wst[k], (mode, k)
+    assert wst["density_lookups"] > 500 * wst["path_samples"]          # hundreds of empty steps per path (many rays miss the grid)
+
+
+@pytest.mark.parametrize("integ", [RATIO, DELTA])
 @pytest.mark.parametrize("regime", ["shipped", "textbook"])
 def test_importance_sampling_output_mode(backend, oracle, cloud64, integ, regime):
     """useImportanceSampling (BaseIntegrator.cpp:66-82): every sample is divided by max(0.1, path pdf),
