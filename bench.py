@@ -359,6 +359,8 @@ def main():
             roofline["valu"] = {"bound": "valu", "achieved": rate / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "unit": "G wave-instr/s",
                                 "frac": rate / VALU_PEAK_WAVE_INSTS_PER_S, "insts_per_launch": pmc["valu_insts_per_launch"],
                                 "source": pmc.get("valu_source")}
+            if pmc.get("valu_lane_utilisation"):
+                roofline["valu"]["lane_utilisation"] = pmc["valu_lane_utilisation"]   # SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)
         out = {
             "metric": "Mpath-samples/sec at 1080p (1/2/4/8 GPU) + density lookups/s vs HBM roofline",
             "value": value,

@@ -62,6 +62,10 @@ if "prof_sq" in out and "SQ_INSTS_VALU" in out["prof_sq"]["counters_sum_over_lau
     sq = out["prof_sq"]
     traffic[workload]["valu_insts_per_launch"] = sq["counters_sum_over_launches"]["SQ_INSTS_VALU"] / sq["launches"]
     traffic[workload]["valu_source"] = f"SQ_INSTS_VALU, profiles/{tag}_bench_pmc_track_kernel.json"
+    c = sq["counters_sum_over_launches"]
+    if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
+        # lanes active per VALU instruction, of 64: what divergence (event phases, the per-trip service blocks) leaves
+        traffic[workload]["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"] / 64.0
 json.dump(traffic, open(tpath, "w"), indent=1)
 print(open(os.path.join(P, f"{tag}_bench_kernel_stats.csv")).read()[:600])
 print(json.dumps(out["derived"], indent=1))
