@@ -65,6 +65,9 @@ WORKLOADS = {
     "config5_marcher_sphere_4k": ("homogeneousRayMarcherImproved", "icosphere", 3840, 2160, 64, "mesh"),
     "config5_marcher_nee_sphere_4k": ("homogeneousRayMarcherNEE", "icosphere", 3840, 2160, 64, "mesh"),
     "perlin_marcher_sphere_1080p": ("heterogeneousPerlinNoise", "icosphere", 1920, 1080, 16, "mesh"),
+    # config 5's other asset: the reference's Models/CornellBox-Sphere.obj (2 192 triangles; arrays in tests/golden/ref_models.npz)
+    "config5_marcher_cornell_4k": ("homogeneousRayMarcherImproved", "cornell_sphere", 3840, 2160, 64, "mesh"),
+    "config5_marcher_nee_cornell_4k": ("homogeneousRayMarcherNEE", "cornell_sphere", 3840, 2160, 64, "mesh"),
     # config 5, tracker leg: the trackers bounded by the mesh (no reference counterpart): the n^3 cloud laid
     # over the 320-triangle sphere, seen by the marchers' camera
     "config5_tracker_ratio_sphere_4k": ("meshRatioTracking", 1024, 3840, 2160, 16, "shipped"),
@@ -189,7 +192,12 @@ def main():
     mesh = None
     if mesh_scene:
         opts = scenes.options_marcher(W, H, spp)
-        mesh = scenes.cube_mesh() if n == "cube" else scenes.icosphere_mesh()
+        if n == "cornell_sphere":
+            mesh = scenes.reference_model(n, os.path.join(ROOT, "tests", "golden", "ref_models.npz"))   # data, not code
+            opts.cameraPosition[:] = (0.0, 0.8, 3.6)     # the box is [-1.02, 1] x [0, 1.59] x [-1.04, 0.99]: fill the frame with it
+            opts.fov = 40.0
+        else:
+            mesh = scenes.cube_mesh() if n == "cube" else scenes.icosphere_mesh()
         be.set_mesh(mesh)                            # BVH resident in HBM before timing
     else:
         be.generate_cloud(n, scenes.cloud_radius(n))     # density resident in HBM before timing
