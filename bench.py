@@ -366,7 +366,10 @@ def main():
             rate = pmc["valu_insts_per_launch"] / avg_launch_s
             roofline["valu"] = {"bound": "valu", "achieved": rate / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "unit": "G wave-instr/s",
                                 "frac": rate / VALU_PEAK_WAVE_INSTS_PER_S, "insts_per_launch": pmc["valu_insts_per_launch"],
-                                "source": pmc.get("valu_source")}
+                                "source": pmc.get("valu_source"),
+                                "note": "peak = one VALU instruction per 2 cycles per SIMD (nominal); compares, conversions, min/max and "
+                                        "three-input bit ops issue at half that rate and log/exp/rcp at a quarter (profiles/r02_ubench_valu.txt), "
+                                        "so a tracking kernel's mix saturates its SIMDs near frac 0.55"}
             if pmc.get("valu_lane_utilisation"):
                 roofline["valu"]["lane_utilisation"] = pmc["valu_lane_utilisation"]   # SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)
         out = {
