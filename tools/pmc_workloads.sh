@@ -5,9 +5,12 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/pmc_wl
-rm -rf $O; mkdir -p $O
+[ -z "$ENTRIES" ] && rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for e in ${ENTRIES:-"config4_delta_4k_256spp_cloud1024 fast" "config3_textbook fast" "config3_delta_1080p_256spp_cloud512 fast" "config4_delta_4k_256spp_cloud1024 local" "config5_tracker_ratio_sphere_4k fast"}; do
+# ENTRIES="workload mode;workload mode" overrides the list (and keeps the files of earlier runs)
+DEFAULT="config4_delta_4k_256spp_cloud1024 fast;config3_textbook fast;config3_delta_1080p_256spp_cloud512 fast;config4_delta_4k_256spp_cloud1024 local;config5_tracker_ratio_sphere_4k fast;gridmarch_simple_1080p_cloud512 fast"
+IFS=';' read -ra LIST <<< "${ENTRIES:-$DEFAULT}"
+for e in "${LIST[@]}"; do
   set -- $e
   w=$1; m=$2; tag=${w}_${m}
   B="python3 $R/bench.py --workload $w --mode $m --steps 1 --warmup 0 --cpu-baseline off --pipeline off"
