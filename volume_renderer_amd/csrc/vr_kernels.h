@@ -937,8 +937,15 @@ struct DdaParams {
 };
 enum { DD_NEED = 0, DD_WALK = 1, DD_EXHAUSTED = 2, DD_SCATTER = 3, DD_ABSORBED = 4, DD_ESCAPED = 5, DD_BLACK = 6 };
 
+// Waves per SIMD: the walk's state (ray, DDA, generator, counters) is some 75 registers.  At eight waves (64 VGPRs) the
+// compiler spilled 96 bytes per lane INSIDE the step loop and every trip paid scratch traffic on top of its own load:
+// six waves without spills are 1.65 x as fast (config 3 textbook 133 -> 81 ms, config 4 764 -> 465 ms); five 5 % slower
+// than six, seven (72 VGPRs, spills again) slower than eight.
+#ifndef VR_DDA_WAVES
+#define VR_DDA_WAVES 6
+#endif
 template <bool TEMP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VR_DDA_WAVES, VR_DDA_WAVES)))
 vr_delta_dda_kernel(const DdaParams p)
 {
     typedef Math<false> M;
