@@ -345,6 +345,8 @@ def main():
         traffic = pmc.get("hbm_bytes_per_launch") if use_pmc else None
         kernel_name = {0: "vr_march_kernel", 1: "vr_march_kernel", 6: "vr_march_kernel", 7: "vr_march_kernel", 4: "vr_gridmarch_kernel",
                        5: "vr_gridmarch_kernel"}.get(integ_id, "vr_track_kernel")
+        if a.mode == "local" and integ == "deltaTracking":
+            kernel_name = "vr_delta_dda_kernel"
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
             "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S, "traffic": traffic,
