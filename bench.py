@@ -281,7 +281,9 @@ def main():
                     "note": "same frame at spp x N samples per pixel, rows r::N per rank; measured after the timed steps"}
     # the same K frames, two in flight: frame k renders on backend k % 2 while frame k - 1 is gathered and copied out
     piped = None
-    want_pipe = a.pipeline == "on" or (a.pipeline == "auto" and not rehearsal and not mesh_scene)
+    # (auto: single-GPU runs only — at N > 1 the extra leg would put a second set of collectives between the timed steps and
+    # the JSON line; `--pipeline on` asks for it explicitly)
+    want_pipe = a.pipeline == "on" or (a.pipeline == "auto" and world == 1 and not rehearsal and not mesh_scene)
     if want_pipe:
         be2 = Backend(local)
         be2.set_mode({"exact": MODE_EXACT, "local": MODE_FAST_LOCAL}.get(a.mode, MODE_FAST))
