@@ -43,7 +43,11 @@ enum {
      * tracker — stepSizeMultiplier 1, stepSizeMin <= 0.01, stepSizeMax >= 1e4, no importance-sampling output —
      * else VR_ERR_UNSUPPORTED.  Statistically equal to FAST up to the smear of one free path; every other
      * integrator renders exactly as in VR_MODE_FAST. */
-    VR_MODE_FAST_LOCAL = 3
+    VR_MODE_FAST_LOCAL = 3,
+    /* The local-majorant delta tracker in EXACT arithmetic: bit-identical (image and counters) to the oracle's
+     * restatement of that estimator (oracle/vr_oracle.c, cast_ray_delta_local, VRO_MATH_SHARED + VRO_RNG_PHILOX).
+     * The parity mode of VR_MODE_FAST_LOCAL; every other integrator renders as in VR_MODE_EXACT_SKIP. */
+    VR_MODE_EXACT_LOCAL = 4
 };
 
 /* ---- life cycle -------------------------------------------------------------------------

@@ -897,6 +897,28 @@ static int mesh_clip(path_ctx* d, iray* r, v3 worg, v3 wdir, float scale, int in
 /* ------------------------------------------------------------------------------------ */
 /* delta tracking (REF integrators/IntegratorDeltaTracking.cpp:11-176)                   */
 /* ------------------------------------------------------------------------------------ */
+/* STUDY SWITCHES (default 0 = the reference's tracker as written; tests/test_local_majorant_oracle.py).  Each turns ONE
+ * thing in which the reference's delta tracker differs from a textbook one into the textbook form, so that the
+ * difference between the reference's image and the local-majorant tracker's (cast_ray_delta_local below) can be
+ * measured instead of attributed:
+ *   VRO_DELTA_LOOKUP_AFTER_STEP  the collision is classified with the density AT the tentative collision, not with the
+ *                                one looked up one free path earlier (REF :55 reads sigma at tFar, :74 advances tFar,
+ *                                :84-98 classify with the old sigma)
+ *   VRO_DELTA_CLAMP_ENTRY        a lookup on the bbox's max face belongs to the last voxel: Ray::clip pads the box to
+ *                                max + 1 (Ray.h:401), so a ray that enters through a max face starts at index max + 1,
+ *                                where getValue is the background, and crosses its first 10 * stepSizeMin in an
+ *                                empty-space step (REF :70-72) */
+static int g_delta_variant = 0;
+void vro_set_delta_variant(int bits) { g_delta_variant = bits; }
+int  vro_get_delta_variant(void) { return g_delta_variant; }
+
+static inline float grid_value_clamped(const vr_grid_desc* g, v3 p)
+{
+    int32_t c[3] = { (int32_t)floorf(p.x), (int32_t)floorf(p.y), (int32_t)floorf(p.z) };
+    for (int a = 0; a < 3; ++a) { if (c[a] < g->bbox_min[a]) c[a] = g->bbox_min[a]; if (c[a] > g->bbox_max[a]) c[a] = g->bbox_max[a]; }
+    return grid_value(g, v3_make((float)c[0], (float)c[1], (float)c[2]));
+}
+
 static v3 cast_ray_delta(path_ctx* d, int mesh_bound)
 {
     const vr_options_pod* o = d->o;
@@ -928,7 +950,9 @@ static v3 cast_ray_delta(path_ctx* d, int mesh_bound)
     while (!terminated && depthRemaining > 0) {                             /* :54 */
         if (++steps > VRO_STEP_LIMIT) { d->st->step_limit_hits++; terminated = 1; break; }
         rng_begin_step(d->rng);
-        float sigma = densityMultiplier * grid_value(grid, ray_at(&iRay, tFar)); /* :55 */
+        const int clamp_entry = (g_delta_variant & VRO_DELTA_CLAMP_ENTRY) != 0;
+        float sigma = densityMultiplier * (clamp_entry ? grid_value_clamped(grid, ray_at(&iRay, tFar))
+                                                       : grid_value(grid, ray_at(&iRay, tFar))); /* :55 */
         d->st->density_lookups++;
         float mu_a = sigma * o->sigma_a;
         float mu_s = sigma * o->sigma_s;
@@ -945,6 +969,11 @@ static v3 cast_ray_delta(path_ctx* d, int mesh_bound)
         tFar += pathLength;                                                 /* :74 */
         if (tFar > iRay.t1) break;                                          /* :77-79 */
         if (sigma <= 0.0f) continue;                                        /* :81-82 */
+        if (g_delta_variant & VRO_DELTA_LOOKUP_AFTER_STEP) {                /* study switch, not the reference */
+            sigma = densityMultiplier * (clamp_entry ? grid_value_clamped(grid, ray_at(&iRay, tFar)) : grid_value(grid, ray_at(&iRay, tFar)));
+            d->st->density_lookups++;
+            mu_a = sigma * o->sigma_a; mu_s = sigma * o->sigma_s; mu_t = mu_a + mu_s;
+        }
 
         float pAbsorption = mu_a / sigma_maj;                               /* :84-86 */
         float pScattering = mu_s / sigma_maj;
@@ -989,6 +1018,191 @@ static v3 cast_ray_delta(path_ctx* d, int mesh_bound)
     }
     if (terminated) return result;                                          /* :170-173 */
     return v3_add(result, opt3(o->backgroundColor));                        /* :175 */
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* delta tracking over per-cell majorants — NO REFERENCE COUNTERPART                      */
+/* ------------------------------------------------------------------------------------ */
+/* Scalar restatement of the estimator behind VR_MODE_FAST_LOCAL / VR_MODE_EXACT_LOCAL (north_star "DensityFields":
+ * a coarse majorant grid walked by a DDA; volume_renderer_amd/csrc/vr_kernels.h, vr_delta_dda_kernel).  What it replaces
+ * in the reference is the ONE global majorant of REF IntegratorDeltaTracking.cpp:44-47; everything around the free-path
+ * sampling follows the reference's delta tracker (prologue :13-52, absorption :101-113, scattering :115-158, the
+ * scatter budget :54 / :175).  The estimator, in the order the kernel executes it, one generator stream per PATH:
+ *   - the grid is cut into cells of (1 << cell_log)^3 voxels from bbox.min; a cell's majorant is the maximum of its
+ *     voxels (padding to whole 8^3 bricks counts as background) times lightRayDensityMultiplier * (sigma_a + sigma_s);
+ *   - the ray walks the cells with a 3-D DDA (tm* = parameter of the cell's far face per axis, td* = per-cell increment);
+ *   - in a cell with majorant mu > 0 one transition of the stream gives two words: free path t' = t - ln(u) / mu from
+ *     the first, the collision type from the second; a free path that ends beyond min(far face, t1) is dropped and the
+ *     walk goes on from the face (the exponential is memoryless) — or ends as escaped at t1; an empty cell is one step;
+ *   - at a tentative collision the density is looked up AT the collision (voxel index clamped into the current cell, so
+ *     that rounding on a face can never pair a voxel with a smaller neighbour's majorant): absorbed if xi * mu < mu_a,
+ *     scattered if xi * mu < mu_t, else null;
+ *   - a scatter takes the next transition of the same stream for sampleHenyeyGreenstein.
+ * VRO_MATH_SHARED + VRO_RNG_PHILOX is bit-identical to the kernel's EXACT build (tests/test_gpu_local_majorant.py). */
+static struct {
+    const vr_grid_desc* grid;
+    int    cell_log, nc[3];
+    float* major;
+} g_local;
+
+/* the backend's rule (vr_backend.hip, render_row_set): cells of 32^3 voxels on grids of 512 and more, 16^3 from 256, else the 8^3 bricks */
+int vro_local_auto_cell_log(const vr_grid_desc* g)
+{
+    int maxdim = 0;
+    for (int a = 0; a < 3; ++a) { int d = g->bbox_max[a] - g->bbox_min[a] + 1; if (d > maxdim) maxdim = d; }
+    return 3 + (maxdim >= 512 ? 2 : (maxdim >= 256 ? 1 : 0));
+}
+void vro_local_majorants_free(void)
+{
+    free(g_local.major);
+    memset(&g_local, 0, sizeof g_local);
+}
+/* per-cell maxima of `g` for cells of (1 << cell_log)^3 voxels; cell_log in [3, 7] */
+int vro_local_majorants_build(const vr_grid_desc* g, int cell_log)
+{
+    if (!g || !g->voxels || cell_log < 3 || cell_log > 7) return VR_ERR_INVALID_ARG;
+    vro_local_majorants_free();
+    int dim[3], pad[3];
+    for (int a = 0; a < 3; ++a) {
+        dim[a] = g->bbox_max[a] - g->bbox_min[a] + 1;
+        pad[a] = (dim[a] + 7) / 8 * 8;                                   /* the backend stores whole 8^3 bricks */
+        g_local.nc[a] = (pad[a] / 8 + (1 << (cell_log - 3)) - 1) >> (cell_log - 3);
+    }
+    size_t n = (size_t)g_local.nc[0] * g_local.nc[1] * g_local.nc[2];
+    g_local.major = (float*)malloc(n * sizeof(float));
+    if (!g_local.major) return VR_ERR_OUT_OF_MEMORY;
+    for (size_t c = 0; c < n; ++c) g_local.major[c] = -INFINITY;
+    for (int i = 0; i < pad[0]; ++i)
+        for (int j = 0; j < pad[1]; ++j)
+            for (int k = 0; k < pad[2]; ++k) {
+                float v = (i < dim[0] && j < dim[1] && k < dim[2]) ? g->voxels[((size_t)i * dim[1] + j) * dim[2] + k] : g->background;
+                float* m = &g_local.major[((size_t)(i >> cell_log) * g_local.nc[1] + (j >> cell_log)) * g_local.nc[2] + (k >> cell_log)];
+                *m = fmaxf(*m, v);
+            }
+    g_local.grid = g; g_local.cell_log = cell_log;
+    return VR_OK;
+}
+
+typedef struct local_dda {
+    float tmx, tmy, tmz, tdx, tdy, tdz;
+    int   bi, bj, bk;
+    float mu;
+} local_dda;
+
+/* kernel: set_ray + enter_brick */
+static void local_dda_start(local_dda* s, const vr_grid_desc* grid, const iray* r, float t, float mu_scale)
+{
+    const int   cl = g_local.cell_log;
+    const float cs = (float)(1 << cl);
+    const v3 q = ray_at(r, t);
+    int c[3] = { ((int32_t)floorf(q.x) - grid->bbox_min[0]) >> cl, ((int32_t)floorf(q.y) - grid->bbox_min[1]) >> cl,
+                 ((int32_t)floorf(q.z) - grid->bbox_min[2]) >> cl };
+    for (int a = 0; a < 3; ++a) c[a] = c[a] < 0 ? 0 : (c[a] >= g_local.nc[a] ? g_local.nc[a] - 1 : c[a]);   /* the first point lies ON the bbox */
+    s->bi = c[0]; s->bj = c[1]; s->bk = c[2];
+    const v3 e = r->eye, dd = r->dir;
+    const float ix = dd.x != 0 ? 1 / dd.x : INFINITY, iy = dd.y != 0 ? 1 / dd.y : INFINITY, iz = dd.z != 0 ? 1 / dd.z : INFINITY;
+    s->tdx = cs * fabsf(ix); s->tdy = cs * fabsf(iy); s->tdz = cs * fabsf(iz);
+    s->tmx = dd.x != 0 ? ((float)(grid->bbox_min[0] + ((c[0] + (dd.x > 0 ? 1 : 0)) << cl)) - e.x) * ix : INFINITY;
+    s->tmy = dd.y != 0 ? ((float)(grid->bbox_min[1] + ((c[1] + (dd.y > 0 ? 1 : 0)) << cl)) - e.y) * iy : INFINITY;
+    s->tmz = dd.z != 0 ? ((float)(grid->bbox_min[2] + ((c[2] + (dd.z > 0 ? 1 : 0)) << cl)) - e.z) * iz : INFINITY;
+    s->mu = g_local.major[((size_t)c[0] * g_local.nc[1] + c[1]) * g_local.nc[2] + c[2]] * mu_scale;
+}
+/* density at p, voxel index clamped into cell (bi, bj, bk); background beyond the bbox (a cell may stick out of it) */
+static float local_cell_value(const vr_grid_desc* g, v3 p, const local_dda* s)
+{
+    const int cl = g_local.cell_log;
+    const int cell[3] = { s->bi, s->bj, s->bk };
+    int32_t v[3] = { (int32_t)floorf(p.x) - g->bbox_min[0], (int32_t)floorf(p.y) - g->bbox_min[1], (int32_t)floorf(p.z) - g->bbox_min[2] };
+    for (int a = 0; a < 3; ++a) {
+        const int32_t lo = cell[a] << cl, hi = lo + (1 << cl) - 1;
+        v[a] = v[a] < lo ? lo : (v[a] > hi ? hi : v[a]);
+        if (v[a] > g->bbox_max[a] - g->bbox_min[a]) return g->background;
+    }
+    int64_t ny = (int64_t)g->bbox_max[1] - g->bbox_min[1] + 1, nz = (int64_t)g->bbox_max[2] - g->bbox_min[2] + 1;
+    return g->voxels[((int64_t)v[0] * ny + v[1]) * nz + v[2]];
+}
+
+static v3 cast_ray_delta_local(path_ctx* d)
+{
+    const vr_options_pod* o = d->o;
+    const vr_grid_desc* grid = d->sc->density;
+    vro_rng* g = d->rng;
+    const float sig_t = o->sigma_a + o->sigma_s;
+    const float mu_scale = o->lightRayDensityMultiplier * sig_t;
+    const int   hasEmission = d->sc->temperature != NULL;                   /* REF :15 */
+    int depthRemaining = (int)o->maxDepth;                                  /* REF :17 */
+
+    iray iRay = ray_world_to_index(grid, d->rayOrigin, d->rayDirection);    /* REF :30-35 */
+    if (!ray_clip(&iRay, grid) || o->maxDepth == 0) return opt3(o->backgroundColor);   /* REF :37-39, :54 */
+
+    float t = iRay.t0;                                                      /* REF :50 */
+    local_dda s;
+    local_dda_start(&s, grid, &iRay, t, mu_scale);
+    uint64_t steps = 0;
+    for (;;) {
+        if (++steps > VRO_STEP_LIMIT) { d->st->step_limit_hits++; return v3_make(0, 0, 0); }
+        const float tface = fminf(fminf(s.tmx, s.tmy), s.tmz);
+        const float te = fminf(tface, iRay.t1);
+        float t_next = INFINITY, xi = 0.0f;
+        if (s.mu > 0.0f) {
+            float u;
+            if (g->mode == VRO_RNG_REFERENCE) {
+                u = vro_reference_get_float(g->mt, 0.00001f, 1.0f);         /* getFloat(0.00001, 1), REF :63 */
+                xi = vro_reference_get_float(g->mt, 0.0f, 1.0f);            /* getFloat(0, 1), REF :93 */
+            } else {
+                uint32_t w[2];
+                vro_xoshiro128p_next2(g->s, w);
+                u = (unit24(w[0]) * (1.0f - 0.00001f)) + 0.00001f;
+                xi = unit24(w[1]);
+            }
+            t_next = t + (-m_logf(u)) / s.mu;
+        }
+        if (!(t_next < te)) {
+            /* no collision inside this cell: on to the next one */
+            t = te;
+            if (tface >= iRay.t1) return opt3(o->backgroundColor);          /* REF :77-79, :175 the ray has left the grid */
+            if (s.tmx <= s.tmy && s.tmx <= s.tmz) { s.bi += iRay.dir.x > 0 ? 1 : -1; s.tmx += s.tdx; }
+            else if (s.tmy <= s.tmz)              { s.bj += iRay.dir.y > 0 ? 1 : -1; s.tmy += s.tdy; }
+            else                                  { s.bk += iRay.dir.z > 0 ? 1 : -1; s.tmz += s.tdz; }
+            if (s.bi < 0 || s.bi >= g_local.nc[0] || s.bj < 0 || s.bj >= g_local.nc[1] || s.bk < 0 || s.bk >= g_local.nc[2])
+                return opt3(o->backgroundColor);                            /* (rounding: the last face and t1 coincide) */
+            s.mu = g_local.major[((size_t)s.bi * g_local.nc[1] + s.bj) * g_local.nc[2] + s.bk] * mu_scale;
+            continue;
+        }
+        /* tentative collision at t_next: real with probability mu_t(x) / mu */
+        t = t_next;
+        d->st->density_lookups++;
+        const float sigma = o->lightRayDensityMultiplier * local_cell_value(grid, ray_at(&iRay, t), &s);
+        const float thr = xi * s.mu;
+        const float mu_a = sigma * o->sigma_a;
+        if (thr < mu_a) {                                                   /* REF :101-113 */
+            v3 colour = opt3(o->mediumColor);
+            if (hasEmission) colour = v3_add(v3_scale(opt3(o->emissionColor), mu_a), colour);
+            return colour;
+        }
+        if (!(thr < sigma * sig_t)) continue;                               /* null collision */
+        /* scattering                                                          REF :115-158 */
+        d->st->scatter_events++;
+        depthRemaining--;
+        float xi1, xi2;
+        if (g->mode == VRO_RNG_REFERENCE) {
+            xi1 = vro_reference_get_float(g->mt, 0.0f, 0.9999f);
+            xi2 = vro_reference_get_float(g->mt, 0.0f, 0.9999f);
+        } else {
+            uint32_t w[2];
+            vro_xoshiro128p_next2(g->s, w);
+            xi1 = (unit24(w[0]) * (0.9999f - 0.0f)) + 0.0f;
+            xi2 = (unit24(w[1]) * (0.9999f - 0.0f)) + 0.0f;
+        }
+        v3 scattered = hg_sample(o->heyneyGreensteinG, d->rayDirection, xi1, xi2);   /* REF :124-127 */
+        v3 point = ray_at(&iRay, t);                                        /* REF :130 */
+        d->rayDirection = scattered;                                        /* REF :146 */
+        iRay = ray_make(point, scattered, 1e-5f, FLT_MAX);                  /* REF :147 */
+        if (!ray_clip(&iRay, grid)) return v3_make(0, 0, 0);                /* REF :150-155 "scattering failed" */
+        if (depthRemaining <= 0) return opt3(o->backgroundColor);           /* REF :54, :175 */
+        t = iRay.t0;                                                        /* REF :157 */
+        local_dda_start(&s, grid, &iRay, t, mu_scale);
+    }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1471,12 +1685,18 @@ static v3 cast_ray(path_ctx* d, int integrator)
     case VR_INTEGRATOR_NANOVDB_EMISSION:                 return cast_ray_grid_marcher(d, 1);
     case VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE:       return cast_ray_marcher(d, 2); /* same castRay walk (:12-60, :155-168) */
     case VR_INTEGRATOR_DENSITY_SAMPLING:                 return cast_ray_density_sampling(d);
+    case VRO_INTEGRATOR_DELTA_LOCAL:                     return cast_ray_delta_local(d);
     default:                                             return cast_ray_delta(d, 0);
     }
 }
 
 static int scene_ok(const vro_scene* sc, int integrator)
 {
+    if (integrator == VRO_INTEGRATOR_DELTA_LOCAL) {
+        if (!sc->density) return VR_ERR_NO_DENSITY;
+        if (g_local.grid != sc->density || !g_local.major) return VR_ERR_INVALID_ARG;   /* vro_local_majorants_build first */
+        return VR_OK;
+    }
     if (integrator < 0 || integrator >= VR_INTEGRATOR_COUNT) return VR_ERR_INVALID_ARG;
     if (integrator == VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE || integrator == VR_INTEGRATOR_DENSITY_SAMPLING) { if (!sc->mesh) return VR_ERR_NO_MESH; }
     else if (integrator == VR_INTEGRATOR_MESH_RATIO_TRACKING || integrator == VR_INTEGRATOR_MESH_DELTA_TRACKING) {

@@ -39,6 +39,12 @@ enum {
                             oracle and GPU agree bit for bit on the same Philox stream */
 };
 
+/* Oracle-only integrator: delta tracking over per-cell majorants (the estimator of VR_MODE_FAST_LOCAL / VR_MODE_EXACT_LOCAL;
+ * no reference counterpart — vr_oracle.c, cast_ray_delta_local).  vro_local_majorants_build(grid, cell_log) first. */
+enum { VRO_INTEGRATOR_DELTA_LOCAL = 100 };
+/* Study switches of the reference-faithful delta tracker (vr_oracle.c, cast_ray_delta); 0 = the reference as written */
+enum { VRO_DELTA_LOOKUP_AFTER_STEP = 1, VRO_DELTA_CLAMP_ENTRY = 2 };
+
 typedef struct vro_scene {
     const vr_grid_desc* density;     /* may be NULL */
     const vr_grid_desc* temperature; /* may be NULL */
@@ -47,6 +53,11 @@ typedef struct vro_scene {
 
 void vro_set_math_mode(int mode);
 int  vro_get_math_mode(void);
+void vro_set_delta_variant(int bits);
+int  vro_get_delta_variant(void);
+int  vro_local_auto_cell_log(const vr_grid_desc* g);
+int  vro_local_majorants_build(const vr_grid_desc* g, int cell_log);
+void vro_local_majorants_free(void);
 
 /* ---- function-level pieces (each cites the reference in vr_oracle.c) ---- */
 void     vro_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -5,6 +5,11 @@ SURVEY 8(c)(iii).  Writes tests/golden/stat_fixtures.npz; tests/test_statistics.
 tests/test_gpu_statistics.py (the HIP path in FAST mode) compare against it.
 
     python tests/golden/make_stat_golden.py            (about 6 minutes on 8 cores)
+    python tests/golden/make_stat_golden.py --ratio-deep [threads]
+        the two ratio-tracking cases again at 65 536 spp -> tests/golden/stat_fixtures_ratio_deep.npz (about an hour on
+        6 cores).  A ratio-tracking sample is heavy-tailed (next-event estimation through g = 0.924 under a light of 1024):
+        4096 of them are too few for the per-pixel mean to be normal, 65 536 are enough for SURVEY 8(c)(iii)'s bar to be
+        asserted as written (tests/test_gpu_statistics.py).
 
 Data only: 64x64 pixels x 3 channels x (mean, stderr) x 4 cases, float32.
 """
@@ -61,5 +66,25 @@ def main():
     np.savez_compressed(os.path.join(HERE, "stat_fixtures.npz"), **out)
 
 
+DEEP_SPP = 65536
+DEEP_CASES = [c for c in CASES if c[1] == 2]
+
+
+def main_ratio_deep(threads):
+    ol.lib().vro_set_math_mode(ol.MATH_LIBM)
+    grid = cloud()
+    scene, _keep = ol.make_scene(density=grid)
+    out = {"spp": np.array(DEEP_SPP), "n": np.array(N)}
+    for name, integ, regime in DEEP_CASES:
+        mean, se = pixel_statistics(scene, options(integ, regime, DEEP_SPP), integ, ol.RNG_REFERENCE, threads=threads)
+        out[name + "_mean"] = mean.astype(np.float32)
+        out[name + "_stderr"] = se.astype(np.float32)
+        print(name, "image mean", mean.mean(), "median relative stderr", float(np.median(se / np.maximum(mean, 1e-9))), flush=True)
+        np.savez_compressed(os.path.join(HERE, "stat_fixtures_ratio_deep.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--ratio-deep":
+        main_ratio_deep(int(sys.argv[2]) if len(sys.argv) > 2 else 6)
+    else:
+        main()

@@ -19,6 +19,9 @@ RNG_PHILOX = 0
 RNG_REFERENCE = 1
 MATH_LIBM = 0
 MATH_SHARED = 1
+DELTA_LOCAL = 100               # VRO_INTEGRATOR_DELTA_LOCAL: the oracle's restatement of VR_MODE_FAST_LOCAL / EXACT_LOCAL
+DELTA_LOOKUP_AFTER_STEP = 1     # study switches of the reference-faithful delta tracker (vro_set_delta_variant)
+DELTA_CLAMP_ENTRY = 2
 
 _f = C.c_float
 _pf = C.POINTER(C.c_float)
@@ -56,6 +59,13 @@ def lib():
     L = C.CDLL(build())
     L.vro_set_math_mode.argtypes = [C.c_int]
     L.vro_get_math_mode.restype = C.c_int
+    L.vro_set_delta_variant.argtypes = [C.c_int]
+    L.vro_get_delta_variant.restype = C.c_int
+    L.vro_local_auto_cell_log.argtypes = [C.POINTER(GridDesc)]
+    L.vro_local_auto_cell_log.restype = C.c_int
+    L.vro_local_majorants_build.argtypes = [C.POINTER(GridDesc), C.c_int]
+    L.vro_local_majorants_build.restype = C.c_int
+    L.vro_local_majorants_free.restype = None
     L.vro_philox4x32_10.argtypes = [_pu32, _pu32, _pu32]
     L.vro_xoshiro128p_next.argtypes = [_pu32]
     L.vro_xoshiro128p_next.restype = C.c_uint32
@@ -133,6 +143,18 @@ def make_scene(density=None, temperature=None, mesh=None):
     if mesh is not None:
         s.mesh = C.pointer(mesh.desc)
     return s, (density, temperature, mesh)
+
+
+def local_majorants(scene, cell_log=None):
+    """Builds the per-cell maxima the oracle's DELTA_LOCAL integrator walks (cells of (1 << cell_log)^3 voxels; default: the
+    backend's rule, vro_local_auto_cell_log).  Returns the cell_log used."""
+    L = lib()
+    if cell_log is None:
+        cell_log = L.vro_local_auto_cell_log(scene.density)
+    rc = L.vro_local_majorants_build(scene.density, cell_log)
+    if rc != 0:
+        raise RuntimeError(f"vro_local_majorants_build failed: {rc}")
+    return cell_log
 
 
 def render(scene, opts, integrator, rng_mode=RNG_PHILOX, seed=0x5EED0001, nthreads=None, want_stats=False):

@@ -1,9 +1,12 @@
-"""VR_MODE_FAST_LOCAL: delta tracking over per-cell majorants (a coarse majorant grid walked by a 3-D DDA) — north_star
-"DensityFields".  Opt-in and NOT the reference's estimator (vr_kernels.h, vr_delta_dda_kernel): it is textbook delta
-tracking, so its tests are the properties textbook delta tracking has and the reference's tracker partly lacks —
-exp(-tau) through any slab (layered ones included), independence of the voxelisation — plus closeness to the
-global-majorant kernel where the two should be close, and the refusal to run where the reference's parameters make its
-tracker something else."""
+"""VR_MODE_FAST_LOCAL / VR_MODE_EXACT_LOCAL: delta tracking over per-cell majorants (a coarse majorant grid walked by a 3-D
+DDA) — north_star "DensityFields".  Opt-in and NOT the reference's estimator (vr_kernels.h, vr_delta_dda_kernel): it is
+textbook delta tracking.  Its oracle is the CPU restatement of the same estimator (oracle/vr_oracle.c,
+cast_ray_delta_local): the EXACT build of the kernel must equal it bit for bit (image and counters), the production
+(FAST) build must meet SURVEY 8(c)(iii)'s per-pixel bar against that oracle's 4096-spp fixture
+(tests/golden/local_fixtures.npz; how the estimator relates to the reference's is measured on the CPU in
+tests/test_local_majorant_oracle.py).  Then the properties textbook delta tracking has and the reference's tracker partly
+lacks — exp(-tau) through any slab (layered ones included), independence of the voxelisation — and the refusal to run
+where the reference's parameters make its tracker something else."""
 import math
 
 import numpy as np
@@ -11,8 +14,17 @@ import pytest
 
 import oracle_lib as ol
 import scenes
-from volume_renderer_amd import (MODE_FAST, MODE_FAST_LOCAL, Backend, BackendError, BackendGroup, Grid, copy_options,
-                                 default_options)
+import os
+import sys
+
+import stat_common as sc
+from volume_renderer_amd import (MODE_EXACT_LOCAL, MODE_FAST, MODE_FAST_LOCAL, Backend, BackendError, BackendGroup, Grid,
+                                 copy_options, default_options)
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_stat_golden as mg  # noqa: E402
+
+LOCAL_FIXTURES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "local_fixtures.npz")
 
 pytestmark = pytest.mark.gpu
 RATIO, DELTA = 2, 3
@@ -23,6 +35,101 @@ def backend():
     b = Backend(0)
     yield b
     b.close()
+
+
+def bitexact(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def oracle_local(oracle, scene, o, cell_log):
+    """The oracle's restatement of the estimator in the arithmetic and streams the EXACT kernel shares."""
+    ol.local_majorants(scene, cell_log)
+    oracle.vro_set_math_mode(ol.MATH_SHARED)
+    try:
+        return ol.render(scene, o, ol.DELTA_LOCAL, rng_mode=ol.RNG_PHILOX, seed=scenes.SEED, want_stats=True)
+    finally:
+        oracle.vro_set_math_mode(ol.MATH_LIBM)
+        oracle.vro_local_majorants_free()
+
+
+def _ragged_grid():
+    """Dims that are no multiples of a brick or a cell (cells stick out of the bbox), a positive background in the
+    padding, holes of zeros (empty cells) and a few negative voxels."""
+    rng = np.random.default_rng(23)
+    n = (37, 50, 29)
+    x, y, z = np.meshgrid(*(np.arange(m, dtype=np.float32) for m in n), indexing="ij")
+    blob = np.sin(x * 0.31) * np.cos(y * 0.23) * np.sin(z * 0.41 + 1.0)
+    vox = np.where(blob > 0.15, blob, 0.0).astype(np.float32)
+    vox[rng.uniform(size=n) < 0.01] = -0.5
+    vox[8:32, 16:48, 0:29] = 0.0                                       # whole 8^3 and 16^3 cells without medium
+    return Grid(vox, bbox_min=(-18, -25, -14), background=0.05)
+
+
+@pytest.mark.parametrize("case", ["cloud_cells8", "cloud_cells32", "ragged_cells8", "ragged_cells16", "rotated_crop_temperature"])
+def test_exact_local_is_bit_identical_to_the_oracle_restatement(backend, oracle, monkeypatch, case):
+    """vr_delta_dda_kernel<.., EXACT> against cast_ray_delta_local: same Philox/xoshiro streams (one per path), same
+    operation order, IEEE divisions and the shared polynomial log / sin / cos — image, tentative collisions (density
+    lookups) and scatter events must be equal bit for bit, for every cell size and on grids whose cells stick out of the
+    bbox."""
+    n = 64
+    temp = None
+    kw = {}
+    if case.startswith("cloud") or case == "rotated_crop_temperature":
+        vox = np.zeros((n, n, n), dtype=np.float32)
+        oracle.vro_make_cloud(n, scenes.cloud_radius(n), ol.fptr(vox), 8)
+        grid = Grid(vox)
+        level = 2 if case == "cloud_cells32" else 0
+        if case == "rotated_crop_temperature":
+            rng = np.random.default_rng(5)
+            temp = Grid((rng.uniform(0, 2, size=(40, 40, 40)) * (rng.uniform(size=(40, 40, 40)) < 0.5)).astype(np.float32), bbox_min=(-20, -20, -20))
+            kw = dict(widthReference=96, heightReference=72, widthStartOffset=30, heightStartOffset=20, cameraPosition=(20.0, 35.0, 60.0),
+                      cameraRotation=(-25.0, 18.0, 3.0), emissionColor=(0.9, 0.4, 0.1), mediumColor=(0.2, 0.3, 0.4),
+                      lightRayDensityMultiplier=1.5, heyneyGreensteinG=0.0)
+            level = 1
+    else:
+        grid = _ragged_grid()
+        level = 1 if case == "ragged_cells16" else 0
+        kw = dict(cameraPosition=(10.0, -6.0, 60.0))
+    o = scenes.options_cloud(DELTA, 64, 48, 40, 4, regime="textbook", **kw)
+    scene, _keep = ol.make_scene(density=grid, temperature=temp)
+    want, wst = oracle_local(oracle, scene, o, 3 + level)
+    monkeypatch.setenv("VR_TUNE_MAJORANT_LEVEL", str(level))
+    backend.set_density(grid, temp)
+    backend.set_mode(MODE_EXACT_LOCAL)
+    backend.set_seed(scenes.SEED)
+    got = backend.render(o, DELTA)
+    st = backend.last_stats()
+    assert bitexact(got, want), f"{np.count_nonzero(got.view(np.uint32) != want.view(np.uint32))} of {got.size} channels differ"
+    for k in ("path_samples", "density_lookups", "scatter_events"):
+        assert st[k] == wst[k], (k, st[k], wst[k])
+    assert st["step_limit_hits"] == 0 and wst["scatter_events"] > 100
+    assert np.count_nonzero(np.any(want != np.array(o.backgroundColor[:]), axis=-1)) > 50
+    # the production build walks the same streams: its frame is the oracle's up to rounding
+    backend.set_mode(MODE_FAST_LOCAL)
+    fast = backend.render(o, DELTA)
+    close = np.isclose(fast, want, rtol=1e-4, atol=1e-7).all(axis=2).mean()
+    print(case, "FAST_LOCAL pixels within 1e-4 of the oracle:", close)
+    assert close > 0.97, close
+
+
+def test_fast_local_meets_the_per_pixel_bar_against_its_oracle(backend):
+    """SURVEY 8(c)(iii) for the local-majorant tracker: 64 frames of 4096 spp with different keys against the oracle's
+    per-pixel mean at 4096 spp, run as the reference runs (mt19937 per row, libm; tests/golden/make_local_golden.py):
+    |z| < 4 on >= 99.9 % of the pixel-channels, image mean within 0.5 %, same spread per pixel."""
+    fx = np.load(LOCAL_FIXTURES)
+    assert int(fx["spp"]) == 4096
+    backend.set_density(mg.cloud())
+    backend.set_mode(MODE_FAST_LOCAL)
+    o = mg.options(DELTA, "textbook")
+    frames = []
+    for k in range(64):
+        backend.set_seed(0xFACE0000 + 977 * k)
+        frames.append(backend.render(o, DELTA).astype(np.float64))
+    r = sc.compare_frames(np.stack(frames), fx["cloud_local_mean"], fx["cloud_local_stderr"])
+    print("FAST_LOCAL against the local-majorant oracle:", r)
+    assert r["image_mean_rel"] <= sc.IMAGE_MEAN_REL, r
+    assert r["frac_z4"] >= sc.PIXEL_FRACTION and r["frac_z3"] > 0.98, r
+    assert 0.9 < r["median_se_ratio"] < 1.1, r
 
 
 def slab_options(spp, **kw):

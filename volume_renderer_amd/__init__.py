@@ -6,5 +6,5 @@ backend.py  ctypes binding of the C-ABI
 """
 from .abi import (INTEGRATORS, Grid, GridDesc, Mesh, MeshDesc, OptionsPod, RenderStats, copy_options,  # noqa: F401
                   default_options, set_options)
-from .backend import (MODE_EXACT, MODE_EXACT_SKIP, MODE_FAST, MODE_FAST_LOCAL, Backend, BackendError, BackendGroup, lib,  # noqa: F401
+from .backend import (MODE_EXACT, MODE_EXACT_LOCAL, MODE_EXACT_SKIP, MODE_FAST, MODE_FAST_LOCAL, Backend, BackendError, BackendGroup, lib,  # noqa: F401
                       rgb_to_u8)

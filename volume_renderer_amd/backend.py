@@ -15,6 +15,7 @@ MODE_EXACT = 0
 MODE_FAST = 1
 MODE_EXACT_SKIP = 2
 MODE_FAST_LOCAL = 3
+MODE_EXACT_LOCAL = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvr_backend.so")

@@ -609,7 +609,7 @@ int validate(vr_backend* b, const vr_options_pod* o, int integrator)
             return fail(b, VR_ERR_INVALID_ARG, "stepSize min %g is below float resolution at ray parameter %g", o->stepSizeMin, tmax);
         if (std::sqrt(diag) / o->stepSizeMin > 1.0e8f)
             return fail(b, VR_ERR_INVALID_ARG, "stepSize min %g needs more than 1e8 steps across the grid", o->stepSizeMin);
-        if (b->mode == VR_MODE_FAST_LOCAL && integrator == VR_INTEGRATOR_DELTA_TRACKING) {
+        if ((b->mode == VR_MODE_FAST_LOCAL || b->mode == VR_MODE_EXACT_LOCAL) && integrator == VR_INTEGRATOR_DELTA_TRACKING) {
             // per-brick majorants change the reference's estimator wherever it scales or clamps its free paths
             if (o->stepSizeMultiplier != 1.0f || o->stepSizeMin > 0.01f || o->stepSizeMax < 1.0e4f)
                 return fail(b, VR_ERR_UNSUPPORTED, "VR_MODE_FAST_LOCAL needs the textbook regime (stepSizeMultiplier 1, stepSizeMin <= 0.01, "
@@ -731,7 +731,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
     b->passes_used = 0;
     b->launches = 0;
     const bool exact = b->mode != VR_MODE_FAST && b->mode != VR_MODE_FAST_LOCAL;
-    const bool local_majorants = b->mode == VR_MODE_FAST_LOCAL && integrator == VR_INTEGRATOR_DELTA_TRACKING;
+    const bool local_majorants = (b->mode == VR_MODE_FAST_LOCAL || b->mode == VR_MODE_EXACT_LOCAL) && integrator == VR_INTEGRATOR_DELTA_TRACKING;
     const bool timed = !noalloc;
 
     for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)per_pass) {
@@ -814,7 +814,8 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 // than the DDA steps, so they run as full as they can (swept: 2001 / 2720 / 3218 / 3574 / 3785 / 3765 / 3631 M samples/s for
                 // 8 / 16 / 24 / 32 / 44 / 52 / 58 on config 3 textbook; the global-majorant kernels peak at 24)
                 dp.round_max = tuned(b->tune_round_max, 64); dp.round_events = tuned(b->tune_round_events, 44);
-                void (*dk)(const DdaParams) = b->has_temperature ? vr_delta_dda_kernel<true> : vr_delta_dda_kernel<false>;
+                void (*dk)(const DdaParams) = exact ? (b->has_temperature ? vr_delta_dda_kernel<true, true> : vr_delta_dda_kernel<false, true>)
+                                                    : (b->has_temperature ? vr_delta_dda_kernel<true, false> : vr_delta_dda_kernel<false, false>);
                 int per_cu = 8;
                 rc = launch_cap(b, dk, dp, per_cu);
                 if (rc) return rc;
@@ -862,7 +863,8 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                                  : (span ? VR_TK5(I, E, S, Q, false, true) : VR_TK5(I, E, S, Q, false, false)))
 #define VR_TRACK_KERNEL(E, S) (ratio ? (is ? VR_TK4(INTEG_RATIO, E, S, true) : VR_TK4(INTEG_RATIO, E, S, false)) \
                                      : (is ? VR_TK4(INTEG_DELTA, E, S, true) : VR_TK4(INTEG_DELTA, E, S, false)))
-            const int kmode = b->mode == VR_MODE_FAST_LOCAL ? VR_MODE_FAST : b->mode;   // (only the plain delta tracker has a local-majorant kernel)
+            // (only the plain delta tracker has a local-majorant kernel: the LOCAL modes render the other trackers as FAST / EXACT_SKIP)
+            const int kmode = b->mode == VR_MODE_FAST_LOCAL ? VR_MODE_FAST : (b->mode == VR_MODE_EXACT_LOCAL ? VR_MODE_EXACT_SKIP : b->mode);
             switch (skip_ok ? kmode : (kmode == VR_MODE_FAST ? -1 : VR_MODE_EXACT)) {
             case -1:                 kern = VR_TRACK_KERNEL(false, false); break;
             case VR_MODE_EXACT:      kern = VR_TRACK_KERNEL(true, false); break;
@@ -1006,7 +1008,7 @@ void vr_backend_destroy(vr_backend* b)
 int vr_backend_set_mode(vr_backend* b, int mode)
 {
     if (!b) return VR_ERR_INVALID_ARG;
-    if (mode != VR_MODE_EXACT && mode != VR_MODE_FAST && mode != VR_MODE_EXACT_SKIP && mode != VR_MODE_FAST_LOCAL)
+    if (mode != VR_MODE_EXACT && mode != VR_MODE_FAST && mode != VR_MODE_EXACT_SKIP && mode != VR_MODE_FAST_LOCAL && mode != VR_MODE_EXACT_LOCAL)
         return fail(b, VR_ERR_INVALID_ARG, "unknown mode %d", mode);
     b->mode = mode;
     return VR_OK;

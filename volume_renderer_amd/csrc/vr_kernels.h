@@ -944,11 +944,14 @@ enum { DD_NEED = 0, DD_WALK = 1, DD_EXHAUSTED = 2, DD_SCATTER = 3, DD_ABSORBED =
 #ifndef VR_DDA_WAVES
 #define VR_DDA_WAVES 6
 #endif
-template <bool TEMP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VR_DDA_WAVES, VR_DDA_WAVES)))
+// EXACT (VR_MODE_EXACT_LOCAL): the arithmetic the oracle's cast_ray_delta_local shares — IEEE divisions and square roots, the
+// polynomial log / sin / cos of vr_math.h — so that the kernel can be compared with a CPU restatement bit for bit; four
+// waves per SIMD.  The production build (FAST) folds constants and uses the hardware's one-ulp forms.
+template <bool TEMP, bool EXACT = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT ? 4 : VR_DDA_WAVES, EXACT ? 4 : VR_DDA_WAVES)))
 vr_delta_dda_kernel(const DdaParams p)
 {
-    typedef Math<false> M;
+    typedef Math<EXACT> M;
     const int      lane = threadIdx.x & 63;
     const uint32_t k0 = p.work.key0, k1 = p.work.key1;
     const float    sig_t = p.sigma_a + p.sigma_s;
@@ -986,8 +989,7 @@ vr_delta_dda_kernel(const DdaParams p)
         bi = i; bj = j; bk = k;
         const f3 e = eye, d = dir;
         const float inf = __builtin_huge_valf();
-        const float ix = d.x != 0 ? __builtin_amdgcn_rcpf(d.x) : inf, iy = d.y != 0 ? __builtin_amdgcn_rcpf(d.y) : inf,
-                    iz = d.z != 0 ? __builtin_amdgcn_rcpf(d.z) : inf;
+        const float ix = d.x != 0 ? M::rcp_(d.x) : inf, iy = d.y != 0 ? M::rcp_(d.y) : inf, iz = d.z != 0 ? M::rcp_(d.z) : inf;
         tdx = cs * fabsf(ix); tdy = cs * fabsf(iy); tdz = cs * fabsf(iz);
         tmx = d.x != 0 ? ((float)(p.density.min[0] + ((i + (d.x > 0 ? 1 : 0)) << cl)) - e.x) * ix : inf;
         tmy = d.y != 0 ? ((float)(p.density.min[1] + ((j + (d.y > 0 ? 1 : 0)) << cl)) - e.y) * iy : inf;
@@ -1022,11 +1024,11 @@ vr_delta_dda_kernel(const DdaParams p)
                 depth_remaining--;
                 uint32_t h0, h1;
                 xoshiro128p_next2(xs0, xs1, xs2, xs3, h0, h1);
-                const f3 scattered = hg_sample<false>(c->g, wdir, in_range(h0, 0.0f, 0.9999f), in_range(h1, 0.0f, 0.9999f));   // :124-127
+                const f3 scattered = hg_sample<EXACT>(c->g, wdir, in_range(h0, 0.0f, 0.9999f), in_range(h1, 0.0f, 0.9999f));   // :124-127
                 const f3 point = ray_at(eye, dir, t);                                         // :130
                 wdir = scattered;                                                             // :146
                 float c0 = 1e-5f, c1 = VR_FLT_MAX;
-                if (!ray_clip<false>(point, scattered, c0, c1, c->bmin, c->bmax1)) st = DD_BLACK;   // :150-155 "scattering failed"
+                if (!ray_clip<EXACT>(point, scattered, c0, c1, c->bmin, c->bmax1)) st = DD_BLACK;   // :150-155 "scattering failed"
                 else if (depth_remaining <= 0) st = DD_ESCAPED;                               // :54, :175
                 else { st = DD_WALK; set_ray(point, scattered, c0, c1); }
             }
@@ -1094,7 +1096,7 @@ vr_delta_dda_kernel(const DdaParams p)
                 const uint32_t cj = c->cam.y0 + c->cam.row_first + r * c->cam.row_stride;
                 n_paths++;
                 // castRay prologue                      IntegratorDeltaTracking.cpp:13-52
-                const f3 wd = primary_direction<false>(c->cam, ci, cj, s);
+                const f3 wd = primary_direction<EXACT>(c->cam, ci, cj, s);
                 wdir = wd;
                 const f3 weye = mk3(c->cam.pos[0], c->cam.pos[1], c->cam.pos[2]);
                 const f3 ieye = mat_mult(c->inv_mat, mk3(weye.x - c->vec[0], weye.y - c->vec[1], weye.z - c->vec[2]));
@@ -1103,7 +1105,7 @@ vr_delta_dda_kernel(const DdaParams p)
                 const float inv_length = M::rcp_(length);
                 const f3 ndir = mk3(inv_length * idir.x, inv_length * idir.y, inv_length * idir.z);
                 float c0 = length * 1e-5f, c1 = VR_FLT_MAX;
-                if (!ray_clip<false>(ieye, ndir, c0, c1, c->bmin, c->bmax1) || c->max_depth == 0) {
+                if (!ray_clip<EXACT>(ieye, ndir, c0, c1, c->bmin, c->bmax1) || c->max_depth == 0) {
                     store_sample(p.work.samples, item, mk3(c->background[0], c->background[1], c->background[2]));   // :37-39
                 } else {
                     st = DD_WALK;
@@ -1129,8 +1131,12 @@ vr_delta_dda_kernel(const DdaParams p)
                 if (mu > 0.0f) {
                     uint32_t w_path;
                     xoshiro128p_next2(xs0, xs1, xs2, xs3, w_path, w_event);
-                    const float u = fmaf((float)(w_path >> 8), (1.0f - 0.00001f) / 16777216.0f, 0.00001f);   // getFloat(0.00001, 1), :63
-                    t_next = fmaf(__builtin_amdgcn_logf(u), -0.6931471805599453f * __builtin_amdgcn_rcpf(mu), t);
+                    if (EXACT) {
+                        t_next = t + M::div_(-M::log_(in_range(w_path, 0.00001f, 1.0f)), mu);          // getFloat(0.00001, 1), :63
+                    } else {
+                        const float u = fmaf((float)(w_path >> 8), (1.0f - 0.00001f) / 16777216.0f, 0.00001f);
+                        t_next = fmaf(__builtin_amdgcn_logf(u), -0.6931471805599453f * __builtin_amdgcn_rcpf(mu), t);
+                    }
                 }
                 if (!(t_next < te)) {
                     // no collision inside this brick: on to the next one
@@ -1148,7 +1154,22 @@ vr_delta_dda_kernel(const DdaParams p)
                     // tentative collision at t_next: real with probability mu_t(x) / mu
                     t = t_next;
                     steps++;
-                    const float sigma = p.light_mult * grid_value_nocache(p.density, ray_at(eye, dir, t));   // :55, at the collision
+                    // :55, at the collision.  The voxel index is clamped into the DDA's cell: on a face rounding may put
+                    // floor(ray(t)) into the neighbour, whose density the cell's majorant does not bound; a cell may also
+                    // stick out of the bbox (background there).
+                    float sigma = p.density.background;
+                    {
+                        const f3      q = ray_at(eye, dir, t);
+                        const int32_t span = (1 << cl) - 1;
+                        int32_t vi = floor_to_int(q.x) - p.density.min[0], vj = floor_to_int(q.y) - p.density.min[1],
+                                vk = floor_to_int(q.z) - p.density.min[2];
+                        vi = max(bi << cl, min(vi, (bi << cl) + span));
+                        vj = max(bj << cl, min(vj, (bj << cl) + span));
+                        vk = max(bk << cl, min(vk, (bk << cl) + span));
+                        if (vi < p.density.dim[0] && vj < p.density.dim[1] && vk < p.density.dim[2])
+                            sigma = p.density.bricks[brick_offset(p.density, (uint32_t)vi, (uint32_t)vj, (uint32_t)vk)];
+                    }
+                    sigma *= p.light_mult;
                     const float thr = (float)(w_event >> 8) * (1.0f / 16777216.0f) * mu;
                     const float mu_a = sigma * p.sigma_a;
                     if (thr < mu_a) { absorbed_mu_a = mu_a; st = DD_ABSORBED; }              // :101-113
