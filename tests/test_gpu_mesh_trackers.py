@@ -105,7 +105,9 @@ def test_mesh_trackers_fast_mode_tracks_the_oracle(backend, oracle, integ):
     got = backend.render(o, integ)
     st = backend.last_stats()
     rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
-    assert np.mean(np.all(rel < 1e-4, axis=-1)) > 0.80
+    frac = float(np.mean(np.all(rel < 1e-4, axis=-1)))
+    print(f"integrator {integ}: {frac:.4f} of the pixels within 1e-4 of the oracle, image mean rel {abs(got.mean() - want.mean()) / want.mean():.2e}")
+    assert frac > (0.995 if integ == MESH_RATIO else 0.999), frac      # measured 0.9998 / 1.0000 (the plain trackers: 0.9990 / 0.9998)
     assert abs(got.mean() - want.mean()) / want.mean() < 5e-3
     assert abs(st["density_lookups"] - wst["density_lookups"]) / wst["density_lookups"] < 5e-3
     assert abs(st["ray_queries"] - wst["ray_queries"]) / wst["ray_queries"] < 5e-3

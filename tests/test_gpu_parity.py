@@ -358,6 +358,75 @@ def test_marchers_exact_mode_is_bit_identical(backend, oracle, mesh_name, integ)
     assert 0.1 < np.mean(np.any(want != bg, axis=-1)) < 0.9   # the medium covers part of the frame
 
 
+GOLDEN_MODELS = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "ref_models.npz")
+CORNELL_VIEW = dict(cameraPosition=(0.0, 0.8, 3.6), fov=40.0)       # looks into the box ([-1.02, 1] x [0, 1.59] x [-1.04, 0.99])
+
+
+@pytest.mark.parametrize("integ", [NEE, IMPROVED, DENSITY])
+def test_marchers_on_the_reference_cornell_box(backend, oracle, integ):
+    """BASELINE config 5's marcher leg on the reference's own Models/CornellBox-Sphere.obj (2 192 triangles, ten shapes,
+    every one a medium since tinyobj defaults `dissolve` to 1): the previous != current object walk of
+    IntegratorHomogeneousRayMarcherNEE.cpp:47-118 over ten shapes — walls are open sheets, so a camera ray enters a
+    "medium" at the back wall and leaves it wherever the same shape is hit again, or never.  Exact mode bit-identical to
+    the brute-force oracle incl. the closest-hit and light-ray counts; FAST within 1e-4 relative of the libm oracle."""
+    mesh = scenes.reference_model("cornell_sphere", GOLDEN_MODELS)
+    assert mesh.tris.shape[0] == 2192 and len(mesh.shape_dissolve) == 10
+    o = scenes.options_marcher(72, 60, 4, cameraPosition=(0.0, 0.45, 2.2), fov=40.0)   # close to the two spheres: a quarter of the pixels march
+    sc, _ = ol.make_scene(mesh=mesh)
+    want, wst = oracle_image(oracle, sc, o, integ)
+    backend.set_mesh(mesh)
+    backend.set_mode(MODE_EXACT)
+    backend.set_seed(scenes.SEED)
+    got = backend.render(o, integ)
+    st = backend.last_stats()
+    assert bitexact(got, want), f"{np.count_nonzero(got.view(np.uint32) != want.view(np.uint32))} of {got.size} channels differ"
+    assert st["ray_queries"] == wst["ray_queries"] and st["shadow_rays"] == wst["shadow_rays"] and st["step_limit_hits"] == 0
+    assert st["ray_queries"] > (2.5 if integ != DENSITY else 2.0) * st["path_samples"]   # entry, exit and (marchers) light rays
+    bg = np.array(o.backgroundColor[:], dtype=np.float32)
+    assert 0.2 < np.mean(np.any(want != bg, axis=-1)) < 0.5            # the spheres' pixels; the walls are open sheets, rays leave through them
+    oracle.vro_set_math_mode(ol.MATH_LIBM)
+    libm = ol.render(sc, o, integ, rng_mode=ol.RNG_PHILOX, seed=scenes.SEED)
+    backend.set_mode(MODE_FAST)
+    fast = backend.render(o, integ)
+    rel = np.abs(fast - libm) / np.maximum(np.abs(libm), 1e-3)
+    frac = float(np.mean(rel.max(axis=2) <= 1e-4))
+    print(f"integrator {integ}: FAST within 1e-4 of the libm oracle on {frac:.4f} of the pixels, worst {rel.max():.2e}")
+    if integ == IMPROVED:
+        assert frac > 0.995                                            # a roulette draw may flip on a rounding tie
+    else:
+        assert rel.max() < 1e-4, rel.max()
+
+
+def test_config5_marcher_4k_frame_properties(backend, oracle):
+    """BASELINE config 5's marcher leg at its frame size (3840 x 2160, CornellBox-Sphere.obj; 1 of 1024 sub-samples):
+    sample count, determinism, 8-way row interleave = the single frame, and three full-width rows bit-identical to the
+    oracle."""
+    import torch
+    W, H = 3840, 2160
+    mesh = scenes.reference_model("cornell_sphere", GOLDEN_MODELS)
+    backend.set_mesh(mesh)
+    backend.set_seed(scenes.SEED)
+    backend.set_mode(MODE_EXACT)
+    o = scenes.options_marcher(W, H, 1, **CORNELL_VIEW)
+    full = backend.render(o, NEE)
+    st = backend.last_stats()
+    assert st["path_samples"] == W * H and st["step_limit_hits"] == 0 and np.isfinite(full).all()
+    assert bitexact(full, backend.render(o, NEE))
+    dev = torch.zeros((H // 8, W, 3), dtype=torch.float32, device="cuda:0")
+    for r in (0, 5):
+        backend.render_row_set_device(o, NEE, r, 8, H // 8, dev.data_ptr())
+        backend.synchronize()
+        assert bitexact(full[r::8], dev.cpu().numpy())
+    sc, _ = ol.make_scene(mesh=mesh)
+    oracle.vro_set_math_mode(ol.MATH_SHARED)
+    try:
+        for j in (H // 2, 700):
+            want, _, _ = ol.render_rows(sc, o, NEE, j, j + 1, rng_mode=ol.RNG_PHILOX, seed=scenes.SEED)
+            assert bitexact(full[j], want[0]), f"row {j}"
+    finally:
+        oracle.vro_set_math_mode(ol.MATH_LIBM)
+
+
 def test_marcher_fast_mode_within_1e4(backend, oracle):
     """north_star: the deterministic marcher matches per pixel within 1e-4 relative."""
     mesh = scenes.icosphere_mesh()

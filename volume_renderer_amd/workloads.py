@@ -82,8 +82,10 @@ def options_cloud(integrator, n, width, height, spp, regime="shipped", **kw):
     """BASELINE configs 2/3 on an n^3 cloud of radius 240/512*n voxels, camera on +z at 2.2 R, fov 45.
 
     regime "shipped": the step parameters of bunny-cloud-configRenderer.xml:9-14 (ratio) /
-    bunny-cloud-deltaTracking-configRenderer.xml:9-14 (delta); "textbook": multiplier 1,
-    min 1e-4 scaled to the grid, max 1e30.
+    bunny-cloud-deltaTracking-configRenderer.xml:9-14 (delta); "textbook": multiplier 1, min 1e-3, max 1e30.
+    (SURVEY 8d sketches min 1e-4; that is below float resolution at the ray parameters of config 4 — ulp(2048) = 2.4e-4, a
+    clamped step would not advance tFar and the reference's loop would never end — so every textbook workload, test and
+    DESIGN.md figure uses 1e-3: free paths are never clamped by it (they are ~1 voxel), empty-space steps are 0.01 voxel.)
     """
     R = cloud_radius(n)
     base = dict(width=width, height=height, widthReference=width, heightReference=height, rayPerPixelCount=spp,
