@@ -237,6 +237,9 @@ def main():
             frame = sched.render(render_rows)
             if rank == 0:
                 host_frame.copy_(frame)              # device -> pinned host, synchronous
+            # every rank: the gather reads `part` on torch's stream, the next frame's kernel writes it on the backend's own
+            # (non-blocking) stream — wait for the gather before launching again (include/vr_backend.h, render_row_set_device)
+            torch.cuda.current_stream().synchronize()
             return frame
 
         for _ in range(warmup):
@@ -308,6 +311,7 @@ def main():
             frame = scheds[k % 2].gather()
             if rank == 0:
                 host_frame.copy_(frame)
+            torch.cuda.current_stream().synchronize()   # the gather has read `part` before launch(k + 2) writes it
 
         for k in range(2):                      # warm-up: both backends' buffers exist
             launch(k); finish(k)

@@ -947,9 +947,27 @@ static v3 cast_ray_delta(path_ctx* d, int mesh_bound)
     int terminated = 0;
     uint64_t steps = 0;
 
+    /* VRO_RNG_PHILOX_GEOM (the FAST kernel's GEOM variant, vr_kernels.h): when EVERY free path is clamped to stepSizeMin
+     * (-ln(0.00001) is the largest draw of :63) the steps are independent Bernoulli trials with P(real collision) = 1 - pNull,
+     * and the walk draws ONE exponential clock instead of two numbers per step: a step costs -ln(pNull), the real collision
+     * is the step at which the clock runs out, and a second number of the same draw decides absorption / scattering.  Same
+     * distribution of every step's outcome as the reference's loop below, another stream.  Restated step by step here. */
+    const int geom = d->rng->mode == VRO_RNG_PHILOX_GEOM && !o->useImportanceSampling &&
+                     sigma_maj > 0.0f && 11.52f * o->stepSizeMultiplier / sigma_maj <= tMin;
+    double geom_clock = 0.0;
+    float  geom_v = 0.0f;
+    int    geom_fresh = 1;            /* a new walk: draw its clock */
+
     while (!terminated && depthRemaining > 0) {                             /* :54 */
         if (++steps > VRO_STEP_LIMIT) { d->st->step_limit_hits++; terminated = 1; break; }
         rng_begin_step(d->rng);
+        if (geom && geom_fresh) {
+            uint32_t w[2];
+            vro_xoshiro128p_next2(d->rng->s, w);
+            geom_clock = -log((double)((unit24(w[0]) * (1.0f - 0.00001f)) + 0.00001f));
+            geom_v = unit24(w[1]);
+            geom_fresh = 0;
+        }
         const int clamp_entry = (g_delta_variant & VRO_DELTA_CLAMP_ENTRY) != 0;
         float sigma = densityMultiplier * (clamp_entry ? grid_value_clamped(grid, ray_at(&iRay, tFar))
                                                        : grid_value(grid, ray_at(&iRay, tFar))); /* :55 */
@@ -960,9 +978,12 @@ static v3 cast_ray_delta(path_ctx* d, int mesh_bound)
 
         float pathLength = 0;
         if (sigma > 0.0f) {                                                 /* :62-69 */
-            pathLength = -m_logf(rng_free_path(d->rng)) / sigma_maj;
-            pathLength *= o->stepSizeMultiplier;
-            pathLength = u_clamp(tMin, tMax, pathLength);
+            if (geom) pathLength = tMin;                                    /* every draw is clamped to it */
+            else {
+                pathLength = -m_logf(rng_free_path(d->rng)) / sigma_maj;
+                pathLength *= o->stepSizeMultiplier;
+                pathLength = u_clamp(tMin, tMax, pathLength);
+            }
         } else {
             pathLength = tMin * 10;                                         /* :71 */
         }
@@ -983,7 +1004,15 @@ static v3 cast_ray_delta(path_ctx* d, int mesh_bound)
         double sampleAttenuation = m_expf(-(pathLength)*mu_t);              /* :88 */
         d->rayPDF = (float)(d->rayPDF * (mu_t * sampleAttenuation));        /* :91 */
 
-        float sample = rng_event(d->rng);                                   /* :93 */
+        float sample;
+        if (geom) {
+            /* the clock: this step costs -ln(pNull); it is a real collision when the clock runs out, and then
+             * `sample` is uniform in [pNull, 1) */
+            geom_clock -= -log((double)pNull);
+            if (geom_clock >= 0.0) sample = -1.0f;                          /* null collision */
+            else { sample = pNull + geom_v * (1.0f - pNull); if (!(sample >= pNull)) sample = pNull; }
+        } else
+            sample = rng_event(d->rng);                                     /* :93 */
         if (sample < pNull) {
             /* null collision */
         } else if (sample < pNull + pAbsorption) {                          /* :101-113 */
@@ -1014,6 +1043,7 @@ static v3 cast_ray_delta(path_ctx* d, int mesh_bound)
                 if (rc == SEG_BLACK || empty) { terminated = 1; break; }
             }
             tFar = iRay.t0;                                                 /* :157 */
+            geom_fresh = 1;
         }
     }
     if (terminated) return result;                                          /* :170-173 */
@@ -1736,7 +1766,7 @@ static void render_pixel(path_ctx* d, int integrator, int i, int j, const float 
         d->rayOrigin = opt3(o->cameraPosition);                                /* :61 */
         d->rayDirection = v3_make(dir[0], dir[1], dir[2]);                     /* :62 */
         d->objectId = -1;                                                      /* :63 */
-        if (d->rng->mode == VRO_RNG_PHILOX) rng_begin_path(d->rng, (uint32_t)i, (uint32_t)j, s);
+        if (d->rng->mode != VRO_RNG_REFERENCE) rng_begin_path(d->rng, (uint32_t)i, (uint32_t)j, s);
         v3 r = cast_ray(d, integrator);
         if (o->useImportanceSampling) {                                        /* :66-69, :75-79 */
             float pdf = d->rayPDF;

@@ -29,8 +29,11 @@ extern "C" {
 /* RNG modes for the render entry points */
 enum {
     VRO_RNG_PHILOX    = 0, /* Philox4x32-10 keyed (pixel, sample, bounce): the GPU path's stream */
-    VRO_RNG_REFERENCE = 1  /* mt19937 seeded per row chunk + uniform_real_distribution<float>
+    VRO_RNG_REFERENCE = 1, /* mt19937 seeded per row chunk + uniform_real_distribution<float>
                               (Utils/RandomGenerator.cpp:4-14, BaseIntegrator.cpp:298) */
+    VRO_RNG_PHILOX_GEOM = 2 /* VRO_RNG_PHILOX, and the delta tracker draws one exponential clock per walk instead of two
+                               numbers per step wherever every free path is clamped to stepSizeMin (the FAST kernel's GEOM
+                               variant; everything else draws as in VRO_RNG_PHILOX) */
 };
 /* Transcendental modes (logf/expf/sinf/cosf inside castRay) */
 enum {

@@ -17,6 +17,7 @@ from volume_renderer_amd.abi import GridDesc, MeshDesc, OptionsPod, RenderStats 
 
 RNG_PHILOX = 0
 RNG_REFERENCE = 1
+RNG_PHILOX_GEOM = 2             # RNG_PHILOX + the one-clock-per-walk draws of the FAST delta kernel where every free path is clamped
 MATH_LIBM = 0
 MATH_SHARED = 1
 DELTA_LOCAL = 100               # VRO_INTEGRATOR_DELTA_LOCAL: the oracle's restatement of VR_MODE_FAST_LOCAL / EXACT_LOCAL

@@ -30,7 +30,7 @@ EXPORTS = [
     "vr_backend_render_row_set_device_noalloc", "vr_backend_set_density_map",
     "vr_group_create", "vr_group_destroy", "vr_group_size", "vr_group_backend", "vr_group_last_error", "vr_group_set_density",
     "vr_group_generate_cloud", "vr_group_set_density_map", "vr_group_set_mesh", "vr_group_set_mode", "vr_group_set_seed",
-    "vr_group_render", "vr_group_render_device", "vr_group_last_stats",
+    "vr_group_render", "vr_group_render_device", "vr_group_last_stats", "vr_group_gather_info",
 ]
 
 
@@ -102,6 +102,7 @@ def lib():
     L.vr_group_render.argtypes = [vp, C.POINTER(OptionsPod), C.c_int, C.POINTER(C.c_float)]
     L.vr_group_render_device.argtypes = [vp, C.POINTER(OptionsPod), C.c_int, vp]
     L.vr_group_last_stats.argtypes = [vp, C.POINTER(RenderStats), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.vr_group_gather_info.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.vr_backend_set_mesh.argtypes = [vp, C.POINTER(MeshDesc)]
     L.vr_backend_set_mode.argtypes = [vp, C.c_int]
     L.vr_backend_set_seed.argtypes = [vp, C.c_uint64]
@@ -322,11 +323,18 @@ class BackendGroup:
     def set_seed(self, seed):
         self._check(self._L.vr_group_set_seed(self._h, int(seed)))
 
-    def render(self, opts, integrator):
+    def render(self, opts, integrator, out=None):
         """BaseIntegrator::render minus tonemap/save over all devices -> float32 (height, width, 3) on the host."""
-        fb = np.zeros((opts.height, opts.width, 3), dtype=np.float32)
+        fb = np.zeros((opts.height, opts.width, 3), dtype=np.float32) if out is None else out
+        assert fb.dtype == np.float32 and fb.shape == (opts.height, opts.width, 3) and fb.flags.c_contiguous
         self._check(self._L.vr_group_render(self._h, C.byref(opts), integrator_id(integrator), fb.ctypes.data_as(C.POINTER(C.c_float))))
         return fb
+
+    def gather_info(self):
+        """{"peers_enabled", "peers_refused", "frame_registered"} of the last gathers (vr_group_gather_info)."""
+        a = (C.c_uint32 * 3)()
+        self._check(self._L.vr_group_gather_info(self._h, a))
+        return {"peers_enabled": int(a[0]), "peers_refused": int(a[1]), "frame_registered": bool(a[2])}
 
     def render_device(self, opts, integrator, device_ptr):
         """The same with the frame gathered at device_ptr (height*width*3 floats) on the group's first GPU."""

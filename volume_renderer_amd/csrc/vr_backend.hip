@@ -281,6 +281,8 @@ struct vr_backend {
     unsigned char*    d_noalloc = nullptr;
 
     // developer knobs (VR_TUNE_*), read at the start of each render call; 0 = built-in default
+    int  tune_no_geom = 0;
+    bool last_geom = false;          // the last tracking launch took the closed-form voxel runs (GEOM)
     int tune_tile_h_log = 0, tune_round_max = 0, tune_round_events = 0, tune_chunk = 0, tune_march_tile_h_log = 0, tune_bvh_leaf = 0, tune_major_level = 0;
     // hipOccupancyMaxActiveBlocksPerMultiprocessor per kernel, asked once
     struct { const void* kernel; int blocks; } occupancy[64]{};
@@ -558,6 +560,7 @@ void read_knobs(vr_backend* b)
     b->tune_major_level = plus1("VR_TUNE_MAJORANT_LEVEL");
     b->tune_round_max = tune_env("VR_TUNE_ROUND_MAX"); b->tune_round_events = tune_env("VR_TUNE_ROUND_EVENTS");
     b->tune_chunk = tune_env("VR_TUNE_CHUNK"); b->tune_bvh_leaf = tune_env("VR_TUNE_BVH_LEAF");
+    b->tune_no_geom = tune_env("VR_TUNE_NO_GEOM");
 }
 
 float ulp_of(float v)
@@ -870,6 +873,21 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             case VR_MODE_EXACT:      kern = VR_TRACK_KERNEL(true, false); break;
             case VR_MODE_EXACT_SKIP: kern = VR_TRACK_KERNEL(true, true); break;
             default:                 kern = VR_TRACK_KERNEL(false, true); break;
+            }
+            // FAST delta tracking with EVERY free path clamped to stepSizeMin (-ln(1e-5) = 11.513 is the largest draw,
+            // IntegratorDeltaTracking.cpp:63-67; true for bunny-cloud-deltaTracking-configRenderer.xml:13): a voxel's steps in one
+            // closed-form run (GEOM, vr_kernels.h).  VR_TUNE_NO_GEOM=1 keeps the step-by-step kernel for an A/B.
+            const bool geom = skip_ok && kmode == VR_MODE_FAST && !ratio && !is && span && p.sigma_maj > 0.0f &&
+                              11.52f * o->stepSizeMultiplier / p.sigma_maj <= o->stepSizeMin && !b->tune_no_geom;
+            b->last_geom = geom;
+            if (geom) {
+                kern = temp ? (mesh_bound ? vr_track_kernel<INTEG_DELTA, false, true, false, true, true, true, true>
+                                          : vr_track_kernel<INTEG_DELTA, false, true, false, true, true, false, true>)
+                            : (mesh_bound ? vr_track_kernel<INTEG_DELTA, false, true, false, false, true, true, true>
+                                          : vr_track_kernel<INTEG_DELTA, false, true, false, false, true, false, true>);
+                // one run per trip and an event every few trips, like the voxel-sized-step kernels
+                p.round_max = tuned(b->tune_round_max, 2 * VR_ROUND_MAX);
+                p.round_events = tuned(b->tune_round_events, mesh_bound ? 4 * VR_ROUND_EVENTS : 2 * VR_ROUND_EVENTS);
             }
 #undef VR_TK5
 #undef VR_TK4
@@ -1287,6 +1305,8 @@ struct vr_backend_group {
     std::vector<vr_backend*> dev;
     std::string              err;
     bool                     rendered = false;
+    bool                     frame_registered = false;   // the last vr_group_render page-locked the caller's frame
+    uint32_t                 peers_enabled = 0, peers_refused = 0;   // of the devices other than the first: peer access to the first GPU
 };
 
 namespace {
@@ -1311,10 +1331,17 @@ int group_fail(vr_backend_group* g, int code, uint32_t index, const vr_backend* 
     } while (0)
 
 // rows i, i+N, ... of the frame on device i, all devices launched before any is waited for; each device then copies
-// its row block to the rows' places in the frame (host memory, or memory of the group's first GPU)
+// its row block to the rows' places in the frame (host memory, or memory of the group's first GPU).
+// A host frame is the caller's `new Vec3f[]` — pageable memory, into which an asynchronous 2-D copy degrades to a
+// synchronous, staged one, device after device.  So the frame is page-locked for the duration of the call
+// (hipHostRegister; silently not when that fails, e.g. for memory that is registered already — then the copies are
+// staged as before).  VR_GROUP_NO_REGISTER=1 keeps the old behaviour for an A/B.
+// Failures: once a device has been launched nothing returns before every launched device has been waited for — the
+// caller may free the frame on error, and copies into it must not be in flight then.
 int group_render(vr_backend_group* g, const vr_options_pod* o, int integrator, float* frame, bool frame_on_device)
 {
     if (!g) return VR_ERR_INVALID_ARG;
+    g->rendered = false;
     if (!o || !frame) { g->err = "options or framebuffer == NULL"; return VR_ERR_INVALID_ARG; }
     const uint32_t N = (uint32_t)g->dev.size(), H = o->height, W = o->width;
     std::vector<uint32_t> count(N, 0);
@@ -1325,37 +1352,46 @@ int group_render(vr_backend_group* g, const vr_options_pod* o, int integrator, f
         if (!rc && count[i]) rc = ensure(b, b->d_rows, b->rows_cap, (size_t)count[i] * W * 3);
         if (rc) return group_fail(g, rc, i, b);
     }
-    for (uint32_t i = 0; i < N; ++i) {
+    const size_t row_bytes = (size_t)W * 3 * sizeof(float);
+    bool registered = false;
+    if (!frame_on_device && H && W) {
+        const char* off = getenv("VR_GROUP_NO_REGISTER");
+        if (!(off && off[0] == '1')) {
+            registered = hipHostRegister(frame, (size_t)H * row_bytes, hipHostRegisterDefault) == hipSuccess;
+            if (!registered) (void)hipGetLastError();
+        }
+    }
+    g->frame_registered = registered;
+    int      first_rc = VR_OK;
+    uint32_t launched = 0;                      // devices [0, launched) have work queued
+    for (uint32_t i = 0; i < N && !first_rc; ++i) {
         vr_backend* b = g->dev[i];
         b->stats = vr_render_stats{}; b->passes_used = 0; b->launches = 0; b->last_counters = nullptr;
-        if (!count[i]) {
-            const int rc = validate(b, o, integrator);      // a device without rows still reports a bad call
-            if (rc) return group_fail(g, rc, i, b);
-            continue;
-        }
-        const int rc = render_row_set(b, o, integrator, i, N, count[i], b->d_rows, false);
-        if (rc) return group_fail(g, rc, i, b);
+        int rc;
+        if (!count[i]) rc = validate(b, o, integrator);      // a device without rows still reports a bad call
+        else rc = render_row_set(b, o, integrator, i, N, count[i], b->d_rows, false);
+        if (rc) first_rc = group_fail(g, rc, i, b);
+        else launched = i + 1;
     }
-    const size_t row_bytes = (size_t)W * 3 * sizeof(float);
-    for (uint32_t i = 0; i < N; ++i) {
+    for (uint32_t i = 0; i < launched && !first_rc; ++i) {
         vr_backend* b = g->dev[i];
         if (!count[i]) continue;
         int rc = use_device(b);
-        if (rc) return group_fail(g, rc, i, b);
+        if (rc) { first_rc = group_fail(g, rc, i, b); break; }
         const hipError_t e = hipMemcpy2DAsync((char*)frame + (size_t)i * row_bytes, (size_t)N * row_bytes, b->d_rows, row_bytes, row_bytes,
                                               count[i], frame_on_device ? hipMemcpyDefault : hipMemcpyDeviceToHost, b->stream);
         if (e != hipSuccess) {
             fail(b, VR_ERR_HIP, "gather of the row block: %s", hipGetErrorString(e));
-            return group_fail(g, VR_ERR_HIP, i, b);
+            first_rc = group_fail(g, VR_ERR_HIP, i, b);
         }
     }
-    int first_rc = VR_OK;
-    for (uint32_t i = 0; i < N; ++i) {          // wait for every device even when one failed
+    for (uint32_t i = 0; i < launched; ++i) {   // wait for every launched device, also after a failure
         vr_backend* b = g->dev[i];
         int rc = use_device(b);
         if (!rc) rc = count[i] ? collect(b) : VR_OK;
         if (rc && !first_rc) first_rc = group_fail(g, rc, i, b);
     }
+    if (registered && hipHostUnregister(frame) != hipSuccess) (void)hipGetLastError();
     g->rendered = first_rc == VR_OK;
     return first_rc;
 }
@@ -1383,11 +1419,18 @@ int vr_group_create(const int* ordinals, uint32_t ndevices, vr_backend_group** o
     for (uint32_t i = 1; i < ndevices; ++i) {
         if (g->dev[i]->device == g->dev[0]->device) continue;
         int can = 0;
+        bool ok = false;
         if (hipDeviceCanAccessPeer(&can, g->dev[i]->device, g->dev[0]->device) == hipSuccess && can) {
             (void)hipSetDevice(g->dev[i]->device);
             const hipError_t e = hipDeviceEnablePeerAccess(g->dev[0]->device, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // the copy then goes through the host
-            else (void)hipGetLastError();
+            ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+        }
+        (void)hipGetLastError();
+        if (ok) g->peers_enabled++;
+        else {
+            // not an error: vr_group_render_device's copies from that GPU then go through the host; counted so that a slow
+            // gather can be diagnosed (vr_group_gather_info)
+            g->peers_refused++;
         }
     }
     *out = g;
@@ -1419,6 +1462,13 @@ int vr_group_render(vr_backend_group* g, const vr_options_pod* o, int integrator
 int vr_group_render_device(vr_backend_group* g, const vr_options_pod* o, int integrator, void* d_rgb)
 {
     return group_render(g, o, integrator, (float*)d_rgb, true);
+}
+
+int vr_group_gather_info(const vr_backend_group* g, uint32_t out[3])
+{
+    if (!g || !out) return VR_ERR_INVALID_ARG;
+    out[0] = g->peers_enabled; out[1] = g->peers_refused; out[2] = g->frame_registered ? 1u : 0u;
+    return VR_OK;
 }
 
 int vr_group_last_stats(vr_backend_group* g, vr_render_stats* stats, float* kernel_ms, uint32_t* kernel_launches)

@@ -352,10 +352,22 @@ struct GeoVec<false> {
 #ifndef VR_MESH_WAVES_LESS
 #define VR_MESH_WAVES_LESS 1
 #endif
-template <int INTEG, bool EXACT, bool SKIP, bool IS, bool TEMP, bool SPAN, bool MESH = false>
+// GEOM (FAST delta tracking, SKIP + SPAN, no IS; chosen by the host when EVERY free path is clamped to stepSizeMin, i.e.
+// -ln(1e-5) * stepSizeMultiplier / sigma_maj <= stepSizeMin — the reference's shipped delta config,
+// bunny-cloud-deltaTracking-configRenderer.xml:13): the walk is then a fixed-step march of stepSizeMin whose steps are
+// independent Bernoulli trials, real collision with probability 1 - pNull(sigma) (IntegratorDeltaTracking.cpp:62-99), and
+// sigma only changes with the voxel.  Instead of ~100 iterations per voxel the kernel takes a voxel's steps in ONE run:
+// the walk carries an exponential clock E = -log2(u), drawn once per walk; a step in a voxel costs -log2(pNull), and the
+// real collision is the step at which the clock runs out (P(no collision in steps 1..m) = prod pNull_i = P(E > sum cost_i):
+// the same distribution as the reference's per-step draws, another stream).  A run is empty_run's arithmetic — t advances
+// exactly as that many float additions would — with the step index of the collision solved for in closed form.  Empty
+// voxels (cost 0, step 10 * stepSizeMin, the skip grid's cube) go through the same code.  The oracle restates the clock
+// step by step (VRO_RNG_PHILOX_GEOM); EXACT modes keep the reference's draw per step.
+template <int INTEG, bool EXACT, bool SKIP, bool IS, bool TEMP, bool SPAN, bool MESH = false, bool GEOM = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VR_TRACK_WAVES(INTEG, EXACT, SPAN) - (MESH && !(EXACT) ? VR_MESH_WAVES_LESS : 0), VR_TRACK_WAVES(INTEG, EXACT, SPAN) - (MESH && !(EXACT) ? VR_MESH_WAVES_LESS : 0))))
 vr_track_kernel(const TrackParams p)
 {
+    static_assert(!GEOM || (INTEG == INTEG_DELTA && !EXACT && SKIP && !IS && SPAN), "GEOM: FAST delta tracking over the skip grid with voxel spans");
     typedef Math<EXACT> M;
     constexpr int  VR_TRIP_ITERS = SPAN ? (INTEG == INTEG_RATIO ? VR_TRIP_ITERS_SPAN_RATIO : VR_TRIP_ITERS_SPAN_DELTA) : VR_TRIP_ITERS_PLAIN;
     const int      lane = threadIdx.x & 63;
@@ -405,6 +417,8 @@ vr_track_kernel(const TrackParams p)
     uint32_t& rng_ts = *(uint32_t*)(cold_lane + 13 * 256);
     uint32_t rng_step = 0;                                 // iterations of the walk so far
     uint32_t xs0 = 1, xs1 = 0, xs2 = 0, xs3 = 0;           // the stream's xoshiro128+ state
+    float    geom_clock = 0.0f;                            // GEOM: what is left of the walk's exponential clock, in bits
+    uint32_t geom_event = 0;                               // GEOM: the word that decides absorption / scattering at the collision
     // density at iRay(tFar), fetched at the END of the previous trip so that its latency hides
     // behind the loop overhead and the other waves of the SIMD
     float    cur_val = 0.0f;
@@ -581,6 +595,11 @@ vr_track_kernel(const TrackParams p)
                     st = ST_FINISHED;
                 } else {
                     t0 = c0; st = ST_WALK;                                                // :179, :189
+                    if (GEOM) {
+                        uint32_t w_path;
+                        xoshiro128p_next2(xs0, xs1, xs2, xs3, w_path, geom_event);
+                        geom_clock = -__builtin_amdgcn_logf(fmaf((float)(w_path >> 8), (1.0f - 0.00001f) / 16777216.0f, 0.00001f));
+                    }
                     set_ray(scatter_p, scattered, c0, c1);
                 }
             }
@@ -695,6 +714,11 @@ vr_track_kernel(const TrackParams p)
                         rng_pixel = (cj << 16) | ci; rng_ts = s; rng_step = 0;
                         seed_stream();
                         pdf = 1.0f;                                                       // :14
+                        if (GEOM) {
+                            uint32_t w_path;
+                            xoshiro128p_next2(xs0, xs1, xs2, xs3, w_path, geom_event);
+                            geom_clock = -__builtin_amdgcn_logf(fmaf((float)(w_path >> 8), (1.0f - 0.00001f) / 16777216.0f, 0.00001f));
+                        }
                         set_ray(ieye, ndir, c0, c1);
                     }
                 }
@@ -710,6 +734,69 @@ vr_track_kernel(const TrackParams p)
         if (st == ST_WALK && rng_step > p.work.step_limit) { n_limit++; st = ST_FINISHED; }   // safety cap, once per round
 #pragma unroll 1
         for (int it = 0; it < p.round_max; ++it) {
+          if constexpr (GEOM) {
+            // one RUN per trip: every step that starts in the current voxel (dense: stepSizeMin each, the clock decides where
+            // the real collision falls) or in the cube of empty voxels around it (10 * stepSizeMin each, no collision)
+            if (st == ST_WALK) {
+                const float sigma = p.light_mult * cur_val;
+                const bool  dense = sigma > 0.0f;
+                const float step = dense ? p.t_min : p.t_min * 10;                            // :62-72, every free path clamped
+                // pNull as the reference rounds it (:84-86), the step's real-collision probability 1 - pNull (exact in float)
+                // and its cost on the clock, -log2(pNull): by series where 1 - pNull is small (v_log_f32 near 1 is not)
+                const float pA = M::div_(sigma * p.sigma_a, p.sigma_maj), pS = M::div_(sigma * p.sigma_s, p.sigma_maj);
+                const float pNull = fmaxf(1.0f - pA - pS, 0.0f);
+                const float pReal = 1.0f - pNull;
+                const float series = pReal * fmaf(pReal, fmaf(pReal, fmaf(pReal, 0.25f, 1.0f / 3.0f), 0.5f), 1.0f) * 1.4426950408889634f;
+                float cost = pReal < 0.05f ? series : -__builtin_amdgcn_logf(pNull);
+                if (!dense) cost = 0.0f;
+                float t_safe = t_span;
+                if (!dense && cur_off != 0xffffffffu && cur_val < -1.5f) t_safe = cube_span(-1.0f - cur_val);
+                t_safe = t_safe < t1 ? t_safe : t1;
+                // empty_run's arithmetic (vr_device.h): kf steps that start AND end inside the box, each adding exactly qu
+                const float    qu = (t + step) - t;
+                const uint32_t tb = __float_as_uint(t);
+                const float    half_ulp = __uint_as_float(tb & 0x7f800000u) * 5.9604644775390625e-08f;
+                const bool     regular = qu > 0.0f && fabsf(qu - step) != half_ulp;
+                const float    t_last = __uint_as_float(tb | 0x7fffffu);
+                const float    t_lim = t_safe < t_last ? t_safe : t_last;
+                float kf = floorf((t_lim - t) * __builtin_amdgcn_rcpf(qu) * 0.999999f) - 1.0f;
+                if (!(regular && kf >= 1.0f) || cur_off == 0xffffffffu) kf = 0.0f;
+                // the step (1-based) at which the clock runs out: the smallest j with j * cost > clock
+                const float jf = fmaxf(floorf(geom_clock * __builtin_amdgcn_rcpf(cost)), 0.0f) + 1.0f;   // cost 0: +inf, cost +inf: 1
+                bool collided = false;
+                if (jf <= kf) {
+                    t = fmaf(jf, qu, t);
+                    rng_step += (uint32_t)jf;
+                    collided = true;
+                } else {
+                    t = fmaf(kf, qu, t);
+                    t += step;                                                                // an ordinary step: may leave the box
+                    rng_step += (uint32_t)kf + 1u;
+                    if (t > t1) st = ST_ESCAPED;                                              // :77-79
+                    else if (jf == kf + 1.0f) collided = true;
+                    else geom_clock = fmaf(-(kf + 1.0f), cost, geom_clock);
+                }
+                if (collided) {
+                    // absorption or scattering, given a real collision: sample uniform in [pNull, 1)     :93-115
+                    if ((float)(geom_event >> 8) * (1.0f / 16777216.0f) * pReal < pA) {
+                        if (TEMP) n_lookups++;                                                // accEmission.getValue (:103)
+                        scatter_len = sigma * p.sigma_a;
+                        st = ST_ABSORBED;
+                    } else {
+                        depth_remaining--;                                                    // :118
+                        n_scatter++;
+                        scatter_p = ray_at(eye, dir, t);                                      // :130
+                        scatter_len = step;
+                        st = ST_SHADOW_DONE;
+                    }
+                }
+            }
+            if (st == ST_WALK) prefetch();
+            const int n_walk = __popcll(__ballot(st == ST_WALK));
+            w_trips++; w_trip_lanes += (unsigned)n_walk;
+            const int n_event = __popcll(__ballot(st >= ST_SCATTER));
+            if (n_event >= p.round_events || n_walk == 0) break;
+          } else {
             bool empty = false;     // this lane's current iteration is an empty-space step, still to be taken
             bool parked = false;    // this lane has left its voxel and waits for the lookup at the end of the trip
 #pragma unroll
@@ -888,6 +975,7 @@ vr_track_kernel(const TrackParams p)
 #endif
             const int n_event = __popcll(__ballot(st >= ST_SCATTER));
             if (n_event >= p.round_events || n_walk == 0) break;
+          }
         }
     }
 
