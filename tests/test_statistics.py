@@ -45,3 +45,28 @@ def test_oracle_philox_streams_meet_the_per_pixel_bar_against_the_reference_sche
     # (the image-mean bar is taken over the whole frame on the GPU; a 16-row band of the ratio tracker's
     # NEE spikes is three times noisier)
     assert r["image_mean_rel"] < 3 * sc.IMAGE_MEAN_REL, r
+
+
+def test_oracle_one_clock_per_walk_meets_the_bar_against_the_reference_scheme(oracle):
+    """VRO_RNG_PHILOX_GEOM — what the FAST delta kernel draws where every free path is clamped to stepSizeMin (the shipped
+    delta config): ONE exponential clock per walk instead of two numbers per step.  Same distribution of every step's
+    outcome (IntegratorDeltaTracking.cpp:62-99), so the same per-pixel bar against the reference-scheme fixture."""
+    fx = np.load(FIXTURES)
+    oracle.vro_set_math_mode(ol.MATH_LIBM)
+    scene, _keep = ol.make_scene(density=mg.cloud())
+    o = mg.options(3, "shipped")
+
+    def row(j):
+        _, ps, st = ol.render_rows(scene, o, 3, j, j + 1, rng_mode=ol.RNG_PHILOX_GEOM, seed=0xC10C, per_sample=True)
+        ps = ps[0].astype(np.float64)
+        return ps.mean(axis=1), ps.std(axis=1, ddof=1) / np.sqrt(ps.shape[1])
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as ex:
+        rows = list(ex.map(row, range(BAND.start, BAND.stop)))
+    mean = np.stack([r[0] for r in rows])
+    se = np.stack([r[1] for r in rows])
+    r = sc.compare(mean, se, fx["delta_shipped_mean"][BAND], fx["delta_shipped_stderr"][BAND])
+    print("delta_shipped, one clock per walk:", r)
+    assert r["frac_z4"] >= sc.PIXEL_FRACTION and r["frac_z3"] > 0.99, r
+    assert r["image_mean_rel"] < sc.IMAGE_MEAN_REL, r

@@ -887,7 +887,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                                           : vr_track_kernel<INTEG_DELTA, false, true, false, false, true, false, true>);
                 // one run per trip and an event every few trips, like the voxel-sized-step kernels
                 p.round_max = tuned(b->tune_round_max, 2 * VR_ROUND_MAX);
-                p.round_events = tuned(b->tune_round_events, mesh_bound ? 4 * VR_ROUND_EVENTS : 2 * VR_ROUND_EVENTS);
+                p.round_events = tuned(b->tune_round_events, mesh_bound ? 56 : 2 * VR_ROUND_EVENTS);   // (swept: config 3 1223 / 1424 / 1476 / 1448 / 1302 M samples/s at 8 / 16 / 24 / 32 / 44; config 5's delta leg 752 / 1117 / 1185 at 24 / 48 / 56)
             }
 #undef VR_TK5
 #undef VR_TK4

@@ -182,6 +182,82 @@ __device__ __forceinline__ int closest_hit(const MeshDev& m, f3 org, f3 dir, flo
     return best_prim == 0xffffffffu ? -1 : (int)best_prim;
 }
 
+// The same query for a wave whose rays are COHERENT (the marchers: an 8x8-pixel tile's primary rays, its light rays): the
+// wave walks ONE node sequence — the union of its lanes' traversals, which is what a wave executes anyway — with the node
+// index in a scalar register, so a node or a triangle is fetched ONCE per wave by the scalar unit (s_load through the
+// constant address space: the BVH is read-only while a kernel runs) instead of 64 times by 64 lanes: the per-lane walk spent
+// ~700 cycles per node visit on the L1 request path for ~100 cycles of arithmetic (profiles/r02_config5_marcher).
+// Per lane nothing changes: a lane whose own slab test fails at node m sits out until the walk reaches m's skip target
+// (`resume`; the order is depth-first, so everything in between is the subtree that lane would have skipped), and a leaf's
+// triangles are tested only by lanes whose own slab test passed — the same triangles against the same best_t as
+// closest_hit, hence the same result bit for bit.  Lanes of different direction octants use different node orders: the
+// octants present in the wave are served one after the other (one for all light rays, rarely more than one for a tile).
+// Must be called by all lanes that are active together; wave-level operations see exactly those.
+typedef const uint32_t __attribute__((address_space(4)))* const_u32p;
+__device__ __forceinline__ const_u32p as_constant(const void* p) { return (const_u32p)(unsigned long long)p; }
+__device__ __forceinline__ int closest_hit_wave(const MeshDev& m, f3 org, f3 dir, float& t_out)
+{
+    const float ix = 1.0f / dir.x, iy = 1.0f / dir.y, iz = 1.0f / dir.z;
+    float    best_t = __builtin_huge_valf();
+    uint32_t best_prim = 0xffffffffu;
+    const uint32_t oct = (dir.x < 0.0f ? 1u : 0u) | (dir.y < 0.0f ? 2u : 0u) | (dir.z < 0.0f ? 4u : 0u);
+    const uint32_t nn = m.nnodes;
+    bool pending = true;
+    while (pending) {
+        const uint32_t uoct = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);
+        if (oct == uoct) {
+            pending = false;
+            const const_u32p nodes = as_constant(m.nodes) + (size_t)uoct * nn * 9u;
+            const const_u32p tris = as_constant(m.tris);
+            uint32_t n = 0;          // wave-uniform
+            uint32_t resume = 0;     // this lane takes part from node `resume` on
+            // (Fetching node n + 1 — where the walk goes whenever some lane hits — beside node n was measured: 30 % SLOWER.
+            // Scalar loads return out of order, so the first use of either waits for both.)
+            while (n < nn) {
+                const const_u32p q = nodes + (size_t)n * 9u;
+                const float lo0 = __uint_as_float(q[0]), lo1 = __uint_as_float(q[1]), lo2 = __uint_as_float(q[2]);
+                const float hi0 = __uint_as_float(q[3]), hi1 = __uint_as_float(q[4]), hi2 = __uint_as_float(q[5]);
+                const uint32_t skip = q[6], first = q[7], count = q[8];
+                const bool act = n >= resume;
+                float ax = (lo0 - org.x) * ix, bx = (hi0 - org.x) * ix;
+                float ay = (lo1 - org.y) * iy, by = (hi1 - org.y) * iy;
+                float az = (lo2 - org.z) * iz, bz = (hi2 - org.z) * iz;
+                float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+                float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_t));
+                const bool hit = act && tn <= tf;
+                if (act && !hit) resume = skip;
+                if (__ballot(hit) != 0ull) {
+                    for (uint32_t k = 0; k < count; ++k) {
+                        const const_u32p tq = tris + (size_t)(first + k) * 10u;
+                        TriDev tr;
+                        tr.v0[0] = __uint_as_float(tq[0]); tr.v0[1] = __uint_as_float(tq[1]); tr.v0[2] = __uint_as_float(tq[2]);
+                        tr.e1[0] = __uint_as_float(tq[3]); tr.e1[1] = __uint_as_float(tq[4]); tr.e1[2] = __uint_as_float(tq[5]);
+                        tr.e2[0] = __uint_as_float(tq[6]); tr.e2[1] = __uint_as_float(tq[7]); tr.e2[2] = __uint_as_float(tq[8]);
+                        tr.prim = tq[9];
+                        float t;
+                        if (hit && tri_hit(tr, org, dir, t) && (t < best_t || (t == best_t && tr.prim < best_prim))) {
+                            best_t = t; best_prim = tr.prim;
+                        }
+                    }
+                    n = n + 1u;
+                } else {
+                    n = skip;
+                }
+                n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+            }
+        }
+    }
+    t_out = best_t;
+    return best_prim == 0xffffffffu ? -1 : (int)best_prim;
+}
+#ifndef VR_MARCH_WAVE_BVH
+#define VR_MARCH_WAVE_BVH 1
+#endif
+__device__ __forceinline__ int closest_hit_march(const MeshDev& m, f3 org, f3 dir, float& t_out)
+{
+    return VR_MARCH_WAVE_BVH ? closest_hit_wave(m, org, dir, t_out) : closest_hit(m, org, dir, t_out);
+}
+
 // Mesh-bounded media for the trackers (VR_INTEGRATOR_MESH_*_TRACKING) — NO REFERENCE COUNTERPART: the reference's
 // trackers clip to the grid bbox only (IntegratorDeltaTracking.cpp:37-39); SURVEY 8(d) config 5 defines the capability.
 // The medium interval of a ray is found by the walk the reference's MARCHERS do before they march
@@ -1343,7 +1419,7 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
             if (depth >= p.max_depth) { result = mk3(0, 0, 0); break; }         // :12-14
             float tfar;
             n_queries++;
-            const int prim = closest_hit(p.mesh, origin, dir, tfar);            // :25
+            const int prim = closest_hit_march(p.mesh, origin, dir, tfar);            // :25
             if (prim < 0) { result = bg; break; }                               // :44
             previous_id = object_id;                                            // :30
             object_id = (int)p.mesh.prim_to_shape[prim];                        // :33
@@ -1388,7 +1464,7 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
                         const f3 lo = add3(sp, scale3(light_dir, 0.001f));      // :112-113
                         float    dl = 0;
                         bool     lit = false;
-                        if (density > 0) { n_queries++; n_light++; lit = closest_hit(p.mesh, lo, light_dir, dl) >= 0; }   // :116-117
+                        if (density > 0) { n_queries++; n_light++; lit = closest_hit_march(p.mesh, lo, light_dir, dl) >= 0; }   // :116-117
                         if (lit) {
                             float       tau = 0;
                             const float num_steps_light = ceilf(dl / step_size);   // :120
@@ -1443,7 +1519,7 @@ __global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
                         const f3 lo = add3(sp, scale3(light_dir, 0.001f));      // :84-85
                         float    dl;
                         n_queries++; n_light++;
-                        if (closest_hit(p.mesh, lo, light_dir, dl) >= 0) {      // :88
+                        if (closest_hit_march(p.mesh, lo, light_dir, dl) >= 0) {      // :88
                             if (IMPROVED) {
                                 const float cos_theta = dot3(nd, light_dir);    // Improved :107
                                 const float la = M::exp_(-dl * density * (p.sigma_a + p.sigma_s));
