@@ -1075,12 +1075,12 @@ static struct {
     float* major;
 } g_local;
 
-/* the backend's rule (vr_backend.hip, render_row_set): cells of 32^3 voxels on grids of 512 and more, 16^3 from 256, else the 8^3 bricks */
+/* the backend's rule (vr_backend.hip, render_row_set): cells of 64^3 voxels on grids of 1024 and more, 32^3 from 512, 16^3 from 256, else the 8^3 bricks */
 int vro_local_auto_cell_log(const vr_grid_desc* g)
 {
     int maxdim = 0;
     for (int a = 0; a < 3; ++a) { int d = g->bbox_max[a] - g->bbox_min[a] + 1; if (d > maxdim) maxdim = d; }
-    return 3 + (maxdim >= 512 ? 2 : (maxdim >= 256 ? 1 : 0));
+    return 3 + (maxdim >= 1024 ? 3 : (maxdim >= 512 ? 2 : (maxdim >= 256 ? 1 : 0)));
 }
 void vro_local_majorants_free(void)
 {
@@ -1137,16 +1137,18 @@ static void local_dda_start(local_dda* s, const vr_grid_desc* grid, const iray* 
     s->tmz = dd.z != 0 ? ((float)(grid->bbox_min[2] + ((c[2] + (dd.z > 0 ? 1 : 0)) << cl)) - e.z) * iz : INFINITY;
     s->mu = g_local.major[((size_t)c[0] * g_local.nc[1] + c[1]) * g_local.nc[2] + c[2]] * mu_scale;
 }
-/* density at p, voxel index clamped into cell (bi, bj, bk); background beyond the bbox (a cell may stick out of it) */
+/* density at p, voxel index clamped into cell (bi, bj, bk) and into the bbox (a cell may stick out of it; the ray's interval does not) */
 static float local_cell_value(const vr_grid_desc* g, v3 p, const local_dda* s)
 {
     const int cl = g_local.cell_log;
     const int cell[3] = { s->bi, s->bj, s->bk };
     int32_t v[3] = { (int32_t)floorf(p.x) - g->bbox_min[0], (int32_t)floorf(p.y) - g->bbox_min[1], (int32_t)floorf(p.z) - g->bbox_min[2] };
     for (int a = 0; a < 3; ++a) {
-        const int32_t lo = cell[a] << cl, hi = lo + (1 << cl) - 1;
-        v[a] = v[a] < lo ? lo : (v[a] > hi ? hi : v[a]);
-        if (v[a] > g->bbox_max[a] - g->bbox_min[a]) return g->background;
+        const int32_t lo = cell[a] << cl, last = g->bbox_max[a] - g->bbox_min[a];
+        int32_t hi = lo + (1 << cl) - 1;
+        if (hi > last) hi = last;
+        v[a] = v[a] > hi ? hi : v[a];
+        v[a] = v[a] < lo ? lo : v[a];
     }
     int64_t ny = (int64_t)g->bbox_max[1] - g->bbox_min[1] + 1, nz = (int64_t)g->bbox_max[2] - g->bbox_min[2] + 1;
     return g->voxels[((int64_t)v[0] * ny + v[1]) * nz + v[2]];

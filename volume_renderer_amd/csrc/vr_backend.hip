@@ -43,7 +43,9 @@ __global__ void __launch_bounds__(256) k_rebrick(const float* __restrict__ dense
         const int bk = (int)(b % nbz); b /= nbz;
         const int bj = (int)(b % nby);
         const int bi = (int)(b / nby);
-        const int i = bi * 8 + (int)(local >> 6), j = bj * 8 + (int)((local >> 3) & 7), k = bk * 8 + (int)(local & 7);
+        int li, lj, lk;
+        brick_local_decode(local, li, lj, lk);
+        const int i = bi * 8 + li, j = bj * 8 + lj, k = bk * 8 + lk;
         float     v = background;
         if (i < dx && j < dy && k < dz) v = dense[((size_t)i * dy + j) * dz + k];
         bricks[o] = v;
@@ -58,7 +60,7 @@ __global__ void __launch_bounds__(256) k_unbrick(const float* __restrict__ brick
         const size_t q = o / dz;
         const int    j = (int)(q % dy), i = (int)(q / dy);
         const size_t b = ((size_t)(i >> 3) * nby + (j >> 3)) * nbz + (k >> 3);
-        dense[o] = bricks[(b << 9) | ((i & 7) << 6) | ((j & 7) << 3) | (k & 7)];
+        dense[o] = bricks[(b << 9) | brick_local((uint32_t)i, (uint32_t)j, (uint32_t)k)];
     }
 }
 // one wave per brick: majorant[b] = max over the brick's 512 voxels
@@ -83,7 +85,7 @@ __global__ void __launch_bounds__(256) k_majorant(const float* __restrict__ bric
 // along j then  d2(j) = min_j' max(|j - j'|, d1(j')),  along i the same over d2.
 __device__ __forceinline__ size_t brick_index(int i, int j, int k, int nby, int nbz)
 {
-    return ((((size_t)(i >> 3) * nby + (j >> 3)) * nbz + (k >> 3)) << 9) | (size_t)(((i & 7) << 6) | ((j & 7) << 3) | (k & 7));
+    return ((((size_t)(i >> 3) * nby + (j >> 3)) * nbz + (k >> 3)) << 9) | (size_t)brick_local((uint32_t)i, (uint32_t)j, (uint32_t)k);
 }
 __global__ void __launch_bounds__(256) k_skip_pass(const float* __restrict__ bricks, const uint8_t* __restrict__ in,
                                                    uint8_t* __restrict__ out, int dx, int dy, int dz, int nbx, int nby, int nbz,
@@ -96,7 +98,9 @@ __global__ void __launch_bounds__(256) k_skip_pass(const float* __restrict__ bri
         const int bk = (int)(b % nbz); b /= nbz;
         const int bj = (int)(b % nby);
         const int bi = (int)(b / nby);
-        const int i = bi * 8 + (int)(local >> 6), j = bj * 8 + (int)((local >> 3) & 7), k = bk * 8 + (int)(local & 7);
+        int li, lj, lk;
+        brick_local_decode(local, li, lj, lk);
+        const int i = bi * 8 + li, j = bj * 8 + lj, k = bk * 8 + lk;
         if (i >= dx || j >= dy || k >= dz) { out[o] = 0; continue; }
         const int c = axis == 2 ? k : (axis == 1 ? j : i), n = axis == 2 ? dz : (axis == 1 ? dy : dx);
         auto at = [&](int cc) -> int {
@@ -135,7 +139,9 @@ __global__ void __launch_bounds__(256) k_cloud(float* __restrict__ bricks, int n
         const int bk = (int)(b % nb); b /= nb;
         const int bj = (int)(b % nb);
         const int bi = (int)(b / nb);
-        const int i = bi * 8 + (int)(local >> 6), j = bj * 8 + (int)((local >> 3) & 7), k = bk * 8 + (int)(local & 7);
+        int li, lj, lk;
+        brick_local_decode(local, li, lj, lk);
+        const int i = bi * 8 + li, j = bj * 8 + lj, k = bk * 8 + lk;
         const float half = 0.5f * (float)n;
         const float px = ((float)i + 0.5f) - half, py = ((float)j + 0.5f) - half, pz = ((float)k + 0.5f) - half;
         const float r = sqrtf(px * px + py * py + pz * pz);
@@ -281,7 +287,7 @@ struct vr_backend {
     unsigned char*    d_noalloc = nullptr;
 
     // developer knobs (VR_TUNE_*), read at the start of each render call; 0 = built-in default
-    int  tune_no_geom = 0;
+    int  tune_no_geom = 0, tune_no_lds_major = 0;
     bool last_geom = false;          // the last tracking launch took the closed-form voxel runs (GEOM)
     int tune_tile_h_log = 0, tune_round_max = 0, tune_round_events = 0, tune_chunk = 0, tune_march_tile_h_log = 0, tune_bvh_leaf = 0, tune_major_level = 0;
     // hipOccupancyMaxActiveBlocksPerMultiprocessor per kernel, asked once
@@ -560,7 +566,7 @@ void read_knobs(vr_backend* b)
     b->tune_major_level = plus1("VR_TUNE_MAJORANT_LEVEL");
     b->tune_round_max = tune_env("VR_TUNE_ROUND_MAX"); b->tune_round_events = tune_env("VR_TUNE_ROUND_EVENTS");
     b->tune_chunk = tune_env("VR_TUNE_CHUNK"); b->tune_bvh_leaf = tune_env("VR_TUNE_BVH_LEAF");
-    b->tune_no_geom = tune_env("VR_TUNE_NO_GEOM");
+    b->tune_no_geom = tune_env("VR_TUNE_NO_GEOM"); b->tune_no_lds_major = tune_env("VR_TUNE_NO_LDS_MAJOR");
 }
 
 float ulp_of(float v)
@@ -808,7 +814,9 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 // config 3 textbook and 1336 / 1720 / 1898 / 1812 / 1421 on config 4 (VR_TUNE_MAJORANT_LEVEL; 0 = the 8^3 bricks)
                 // (a sixteenth of the grid's largest extent, between 8 and 32 voxels: small grids keep the bricks)
                 const int maxdim = std::max(b->grid.dim[0], std::max(b->grid.dim[1], b->grid.dim[2]));
-                const int auto_level = maxdim >= 512 ? 2 : (maxdim >= 256 ? 1 : 0);
+                // (from 1024 voxels on: 64^3-voxel cells, whose grid of at most 4096 cells the kernel keeps in LDS — measured on
+                // config 4: 4405 M samples/s against 4351 for 32^3-voxel cells read through L2 and 4345 for 64^3 through L2)
+                const int auto_level = maxdim >= 1024 ? 3 : (maxdim >= 512 ? 2 : (maxdim >= 256 ? 1 : 0));
                 const int level = b->tune_major_level > 0 ? std::min(b->tune_major_level - 1, VR_MAJOR_LEVELS - 1) : auto_level;
                 dp.major = b->d_major + b->major_off[level]; dp.cell_log = 3 + level;
                 for (int a = 0; a < 3; ++a) dp.nc[a] = b->major_nc[level][a];
@@ -817,8 +825,10 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 // than the DDA steps, so they run as full as they can (swept: 2001 / 2720 / 3218 / 3574 / 3785 / 3765 / 3631 M samples/s for
                 // 8 / 16 / 24 / 32 / 44 / 52 / 58 on config 3 textbook; the global-majorant kernels peak at 24)
                 dp.round_max = tuned(b->tune_round_max, 64); dp.round_events = tuned(b->tune_round_events, 44);
+                const bool lds_major = !exact && !b->tune_no_lds_major && (uint64_t)dp.nc[0] * dp.nc[1] * dp.nc[2] <= VR_DDA_LDS_CELLS;
                 void (*dk)(const DdaParams) = exact ? (b->has_temperature ? vr_delta_dda_kernel<true, true> : vr_delta_dda_kernel<false, true>)
-                                                    : (b->has_temperature ? vr_delta_dda_kernel<true, false> : vr_delta_dda_kernel<false, false>);
+                                            : lds_major ? (b->has_temperature ? vr_delta_dda_kernel<true, false, true> : vr_delta_dda_kernel<false, false, true>)
+                                                        : (b->has_temperature ? vr_delta_dda_kernel<true, false> : vr_delta_dda_kernel<false, false>);
                 int per_cu = 8;
                 rc = launch_cap(b, dk, dp, per_cu);
                 if (rc) return rc;

@@ -200,10 +200,28 @@ struct GridDev {
     int32_t      nb[3];  // bricks per axis
     float        background;
 };
+// position of voxel (i & 7, j & 7, k & 7) inside its brick, and back.  -DVR_BRICK_MORTON is an experiment: a
+// 64-byte line then holds 2 x 2 x 4 voxels instead of 1 x 2 x 8.
+__host__ __device__ __forceinline__ uint32_t brick_local(uint32_t i, uint32_t j, uint32_t k)
+{
+#ifdef VR_BRICK_MORTON
+    return ((i & 6u) << 6) | ((j & 6u) << 4) | ((k & 4u) << 2) | ((i & 1u) << 3) | ((j & 1u) << 2) | (k & 3u);
+#else
+    return ((i & 7u) << 6) | ((j & 7u) << 3) | (k & 7u);
+#endif
+}
+__host__ __device__ __forceinline__ void brick_local_decode(uint32_t local, int& i, int& j, int& k)
+{
+#ifdef VR_BRICK_MORTON
+    i = (int)(((local >> 6) & 6u) | ((local >> 3) & 1u)); j = (int)(((local >> 4) & 6u) | ((local >> 2) & 1u)); k = (int)(((local >> 2) & 4u) | (local & 3u));
+#else
+    i = (int)(local >> 6); j = (int)((local >> 3) & 7u); k = (int)(local & 7u);
+#endif
+}
 __device__ __forceinline__ uint32_t brick_offset(const GridDev& g, uint32_t i, uint32_t j, uint32_t k)
 {
     uint32_t b = ((i >> 3) * (uint32_t)g.nb[1] + (j >> 3)) * (uint32_t)g.nb[2] + (k >> 3);
-    return (b << 9) | ((i & 7u) << 6) | ((j & 7u) << 3) | (k & 7u);
+    return (b << 9) | brick_local(i, j, k);
 }
 
 // ---- runs of empty-space steps ---------------------------------------------------------------

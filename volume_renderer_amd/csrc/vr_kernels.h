@@ -1111,11 +1111,22 @@ enum { DD_NEED = 0, DD_WALK = 1, DD_EXHAUSTED = 2, DD_SCATTER = 3, DD_ABSORBED =
 // EXACT (VR_MODE_EXACT_LOCAL): the arithmetic the oracle's cast_ray_delta_local shares — IEEE divisions and square roots, the
 // polynomial log / sin / cos of vr_math.h — so that the kernel can be compared with a CPU restatement bit for bit; four
 // waves per SIMD.  The production build (FAST) folds constants and uses the hardware's one-ulp forms.
-template <bool TEMP, bool EXACT = false>
+// LDSMAJ (north_star "majorant bricks staged in LDS"): when the majorant grid has at most VR_DDA_LDS_CELLS cells every
+// block copies it into LDS once (16 KB; with the 8 KB of event state six blocks still fit a CU) and the DDA reads a cell's
+// majorant from there instead of from L2 — the walk enters a new cell on two trips out of three and waits for that load.
+#define VR_DDA_LDS_CELLS 4096
+template <bool TEMP, bool EXACT = false, bool LDSMAJ = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT ? 4 : VR_DDA_WAVES, EXACT ? 4 : VR_DDA_WAVES)))
 vr_delta_dda_kernel(const DdaParams p)
 {
     typedef Math<EXACT> M;
+    __shared__ float s_major[LDSMAJ ? VR_DDA_LDS_CELLS : 1];
+    if (LDSMAJ) {
+        const uint32_t ncells = (uint32_t)p.nc[0] * (uint32_t)p.nc[1] * (uint32_t)p.nc[2];
+        for (uint32_t i = threadIdx.x; i < ncells; i += 256u) s_major[i] = p.major[i];
+        __syncthreads();
+    }
+    auto major_at = [&](uint32_t idx) -> float { return LDSMAJ ? s_major[idx] : p.major[idx]; };
     const int      lane = threadIdx.x & 63;
     const uint32_t k0 = p.work.key0, k1 = p.work.key1;
     const float    sig_t = p.sigma_a + p.sigma_s;
@@ -1158,7 +1169,7 @@ vr_delta_dda_kernel(const DdaParams p)
         tmx = d.x != 0 ? ((float)(p.density.min[0] + ((i + (d.x > 0 ? 1 : 0)) << cl)) - e.x) * ix : inf;
         tmy = d.y != 0 ? ((float)(p.density.min[1] + ((j + (d.y > 0 ? 1 : 0)) << cl)) - e.y) * iy : inf;
         tmz = d.z != 0 ? ((float)(p.density.min[2] + ((k + (d.z > 0 ? 1 : 0)) << cl)) - e.z) * iz : inf;
-        mu = p.major[((uint32_t)i * (uint32_t)p.nc[1] + (uint32_t)j) * (uint32_t)p.nc[2] + (uint32_t)k] * mu_scale;
+        mu = major_at(((uint32_t)i * (uint32_t)p.nc[1] + (uint32_t)j) * (uint32_t)p.nc[2] + (uint32_t)k) * mu_scale;
     };
     // start a walk along (e, d) over [a, b]: the cell of its first point
     auto set_ray = [&](f3 e, f3 d, float a, float b) {
@@ -1312,26 +1323,25 @@ vr_delta_dda_kernel(const DdaParams p)
                         else                          { bk += dir.z > 0 ? 1 : -1; tmz += tdz; }
                         if ((uint32_t)bi >= (uint32_t)p.nc[0] || (uint32_t)bj >= (uint32_t)p.nc[1] || (uint32_t)bk >= (uint32_t)p.nc[2])
                             st = DD_ESCAPED;                                                  // (rounding: the last face and t1 coincide)
-                        else mu = p.major[((uint32_t)bi * (uint32_t)p.nc[1] + (uint32_t)bj) * (uint32_t)p.nc[2] + (uint32_t)bk] * mu_scale;
+                        else mu = major_at(((uint32_t)bi * (uint32_t)p.nc[1] + (uint32_t)bj) * (uint32_t)p.nc[2] + (uint32_t)bk) * mu_scale;
                     }
                 } else {
                     // tentative collision at t_next: real with probability mu_t(x) / mu
                     t = t_next;
                     steps++;
                     // :55, at the collision.  The voxel index is clamped into the DDA's cell: on a face rounding may put
-                    // floor(ray(t)) into the neighbour, whose density the cell's majorant does not bound; a cell may also
-                    // stick out of the bbox (background there).
-                    float sigma = p.density.background;
+                    // floor(ray(t)) into the neighbour, whose density the cell's majorant does not bound; and into the bbox
+                    // (a cell may stick out of it; the ray's interval does not)
+                    float sigma;
                     {
                         const f3      q = ray_at(eye, dir, t);
                         const int32_t span = (1 << cl) - 1;
                         int32_t vi = floor_to_int(q.x) - p.density.min[0], vj = floor_to_int(q.y) - p.density.min[1],
                                 vk = floor_to_int(q.z) - p.density.min[2];
-                        vi = max(bi << cl, min(vi, (bi << cl) + span));
-                        vj = max(bj << cl, min(vj, (bj << cl) + span));
-                        vk = max(bk << cl, min(vk, (bk << cl) + span));
-                        if (vi < p.density.dim[0] && vj < p.density.dim[1] && vk < p.density.dim[2])
-                            sigma = p.density.bricks[brick_offset(p.density, (uint32_t)vi, (uint32_t)vj, (uint32_t)vk)];
+                        vi = max(bi << cl, min(vi, min((bi << cl) + span, p.density.dim[0] - 1)));
+                        vj = max(bj << cl, min(vj, min((bj << cl) + span, p.density.dim[1] - 1)));
+                        vk = max(bk << cl, min(vk, min((bk << cl) + span, p.density.dim[2] - 1)));
+                        sigma = p.density.bricks[brick_offset(p.density, (uint32_t)vi, (uint32_t)vj, (uint32_t)vk)];
                     }
                     sigma *= p.light_mult;
                     const float thr = (float)(w_event >> 8) * (1.0f / 16777216.0f) * mu;
