@@ -347,8 +347,18 @@ struct TrackParams {
 enum {
     ST_NEED = 0, ST_WALK = 1, ST_EXHAUSTED = 2,
     // events, served by the event phase (every state >= ST_SCATTER)
-    ST_SCATTER = 3, ST_SHADOW_DONE = 4, ST_FINISHED = 5, ST_ESCAPED = 6, ST_ABSORBED = 7
+    ST_SCATTER = 3, ST_SHADOW_DONE = 4, ST_FINISHED = 5, ST_ESCAPED = 6, ST_ABSORBED = 7,
+    ST_COLLIDED = 8   // FLAT iterations: a real collision whose kind (absorption / scattering) the event phase works out
 };
+// FLAT iterations (FAST kernels): the step loop's iteration as straight-line code.  The scalar unit — ONE per CU, shared by
+// its four SIMDs — is the kernel's other bottleneck: every divergent `if` costs s_and_saveexec / s_cbranch_execz / s_or exec
+// plus the mask arithmetic around it, a trip was 310 vector and 230 scalar instructions, and that mix issues at 1.10 vector
+// and 0.82 scalar instructions per CU cycle against 1.48 for vector code alone (tools/ubench_salu.hip).  So the iteration
+// decides with selects, a walk that leaves its segment or collides only changes state, and the bookkeeping of a real
+// collision (its kind, the scatter point, the budget) moves to the event phase, where all waiting lanes are served together.
+#ifndef VR_FLAT_ITER
+#define VR_FLAT_ITER 1
+#endif
 #define VR_ROUND_MAX 48      // step-loop trips before the event phase runs regardless
 #define VR_ROUND_EVENTS 12   // ... or as soon as this many lanes wait for it
 // Iterations of the reference's loop per trip.  A trip ends with ONE empty-space service and ONE voxel
@@ -446,6 +456,7 @@ vr_track_kernel(const TrackParams p)
     static_assert(!GEOM || (INTEG == INTEG_DELTA && !EXACT && SKIP && !IS && SPAN), "GEOM: FAST delta tracking over the skip grid with voxel spans");
     typedef Math<EXACT> M;
     constexpr int  VR_TRIP_ITERS = SPAN ? (INTEG == INTEG_RATIO ? VR_TRIP_ITERS_SPAN_RATIO : VR_TRIP_ITERS_SPAN_DELTA) : VR_TRIP_ITERS_PLAIN;
+    constexpr bool FLAT = VR_FLAT_ITER && !EXACT && !GEOM && !(INTEG == INTEG_RATIO && TEMP);
     const int      lane = threadIdx.x & 63;
     const uint32_t k0 = p.work.key0, k1 = p.work.key1;
     // FAST arithmetic: constants of the step loop folded once (wave-uniform)
@@ -567,6 +578,29 @@ vr_track_kernel(const TrackParams p)
     for (;;) {
         // =========================== event phase ===========================
         w_phases++;
+        // (-1) FLAT iterations: real collisions of the camera walk, left undecided by the step loop.  The lane kept the event
+        // word in cur_off and the step's length in t_span (both dead for a walk that has collided: its next ray resets them).
+        if (FLAT && __any(st == ST_COLLIDED)) {
+            if (st == ST_COLLIDED) {
+                const float sigma = p.light_mult * cur_val;
+                const float pA = sigma * fast_pa24, pS = sigma * fast_ps24;
+                const float pNull = fmaxf(16777216.0f - pA - pS, 0.0f);
+                const float sample = (float)(cur_off >> 8);
+                if (sample < pNull + pA) {
+                    // absorption: the medium colour is added below                          :127-131 (delta :101-113)
+                    if (INTEG == INTEG_DELTA && TEMP) n_lookups++;               // accEmission.getValue, result unused (delta :103)
+                    scatter_len = sigma * p.sigma_a;
+                    st = ST_ABSORBED;
+                } else {
+                    // scattering                                                            :133-191 (delta :115-158)
+                    depth_remaining--;                                                        // :136
+                    n_scatter++;
+                    scatter_p = ray_at(eye, dir, t);                                          // :162 (delta :130)
+                    scatter_len = t_span;
+                    st = INTEG == INTEG_DELTA ? ST_SHADOW_DONE : ST_SCATTER;
+                }
+            }
+        }
         // (0) walks that escaped or were absorbed add their constant colour
         if (__any(st >= ST_ESCAPED)) {
             if (st >= ST_ESCAPED) {
@@ -879,6 +913,51 @@ vr_track_kernel(const TrackParams p)
             for (int half = 0; half < VR_TRIP_ITERS; ++half) {   // (`half`: the trips once had two)
                 if (st != ST_WALK || empty || parked) continue;
                 const bool in_shadow = (INTEG == INTEG_RATIO) && shadow;
+                if constexpr (FLAT) {
+                    const float mult = in_shadow ? p.shadow_mult : p.light_mult;
+                    const float sigma = mult * cur_val;                                       // :71 / :238
+                    const bool  roulette = INTEG == INTEG_RATIO && !in_shadow && faint(T);
+                    if (!roulette && !(sigma > 0.0f)) { empty = true; continue; }
+                    uint32_t w_path, w_event;
+                    xoshiro128p_next2(xs0, xs1, xs2, xs3, w_path, w_event);
+                    if (roulette) {                                                           // :57-69 (rare)
+                        if (roulette16(w_path, w_event) < 0.75f) { st = ST_FINISHED; continue; }
+                        T -= 2.0f;
+                        if (!(sigma > 0.0f)) { empty = true; continue; }
+                    }
+                    const float tmin = in_shadow ? p.t_min * 5 : p.t_min;                     // :216
+                    const float u = fmaf((float)(w_path >> 8), (1.0f - 0.00001f) / 16777216.0f, 0.00001f);
+                    // (what follows derives c, the null threshold and the depth per length from sigma in every iteration; keeping the
+                    // three per voxel, worked out by the lookup, was measured: 12 bytes of spills and 0.5-3 % slower)
+                    const float c = in_shadow ? fast_c_ln * __builtin_amdgcn_rcpf(sigma * fast_sig_t) : fast_c_cam;
+                    const float len = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(u) * c, tmin, p.t_max);   // :80-82 / :247-249
+                    t += len;                                                                 // :88 / :255
+                    rng_step += 1;
+                    const bool exited = t > t1;                                               // :91 / :258
+                    if (half + 1 < VR_TRIP_ITERS) {
+                        if (SPAN) parked = !exited && !(t < t_span);
+                        else if (!exited) prefetch();
+                    }
+                    // the step's optical depth in bits (nothing for the step that leaves the segment)  :103-105 / :266-269
+                    const float att = (INTEG == INTEG_RATIO && !exited) ? len * (sigma * fast_sig_t2) : 0.0f;
+                    if (IS && !in_shadow && !exited) pdf *= (sigma * fast_sig_t) * __builtin_amdgcn_exp2f(-(len * (sigma * fast_sig_t2)));
+                    // camera walk: null collision?                                           :98-100, :108
+                    const float pNull = fmaxf(16777216.0f - sigma * fast_pa24 - sigma * fast_ps24, 0.0f);
+                    const bool  real = !in_shadow && !exited && !((float)(w_event >> 8) < pNull);
+                    if (INTEG == INTEG_RATIO) {
+                        const float ts = Tsh + att;
+                        T = in_shadow ? T : T + att;
+                        Tsh = in_shadow ? ts : Tsh;
+                    }
+                    st = exited ? (in_shadow ? (uint32_t)ST_SHADOW_DONE : (uint32_t)ST_ESCAPED) : (real ? (uint32_t)ST_COLLIDED : st);
+                    cur_off = real ? w_event : cur_off;      // the event phase decides absorption / scattering from it
+                    t_span = real ? len : t_span;            // ... and needs the step's length (scatter_len)
+                    if (INTEG == INTEG_RATIO && in_shadow && !exited && Tsh > DEPTH_ROULETTE) {   // :272-281 (rare)
+                        if (in_range(w_event, 0.0f, 1.0f) < 0.75f) { Tsh = __builtin_inff(); st = ST_SHADOW_DONE; }
+                        else Tsh -= 2.0f;
+                    }
+                    continue;
+                }
 
                 // sigma = multiplier * acc.getValue(Coord::Floor(iRay(tFar)))                :71 / :238
                 const float mult = in_shadow ? p.shadow_mult : p.light_mult;
@@ -1044,6 +1123,9 @@ vr_track_kernel(const TrackParams p)
 #endif
             // experiment: trips that ran the empty-space block, and the lanes in it whose voxel has a distance of at least VR_EMPTY_EXP_D
             if (__any(empty)) { w_trips++; w_trip_lanes += (unsigned)__popcll(__ballot(empty && !(cur_val > -(float)VR_EMPTY_EXP_D))); }
+#elif defined(VR_SHADOW_EXP)
+            // experiment: trips in which no walking lane is on a camera walk, and the camera-walking lanes over all trips
+            { const unsigned long long cam = __ballot(st == ST_WALK && !shadow); if (cam == 0ull) w_trips++; w_trip_lanes += (unsigned)__popcll(cam); }
 #elif defined(VR_PARK_EXP)
             if (__any(parked)) { w_trips++; w_trip_lanes += (unsigned)__popcll(__ballot(parked)); }  // experiment: trips with lanes that left their voxel early
 #else
