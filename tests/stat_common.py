@@ -46,8 +46,10 @@ def blocks(a, b):
     return a.reshape(*lead, h // b, b, w // b, b, c).mean(axis=(-4, -2))
 
 
-def compare_frames(frames, ref_mean, ref_se=None, block=1):
-    """frames: (K, H, W, 3) float64, K independent renders at the reference's sample count."""
+def compare_frames(frames, ref_mean, ref_se=None, block=1, ref_samples_per_frame=1.0, own_se=False):
+    """frames: (K, H, W, 3) float64, K independent renders; the reference mean was taken over `ref_samples_per_frame` times
+    the samples of one frame (1: the reference's sample count; 16: the 65 536-spp ratio fixtures against 4096-spp frames),
+    so its variance is the frames' spread squared over that factor."""
     frames = np.asarray(frames, dtype=np.float64)
     ref_mean = np.asarray(ref_mean, dtype=np.float64)
     if block > 1:
@@ -57,7 +59,11 @@ def compare_frames(frames, ref_mean, ref_se=None, block=1):
     k = frames.shape[0]
     mean = frames.mean(axis=0)
     s = frames.std(axis=0, ddof=1)
-    den = np.sqrt(s ** 2 * (1.0 + 1.0 / k) + (1e-5 * np.abs(ref_mean)) ** 2)
+    den = np.sqrt(s ** 2 * (1.0 / ref_samples_per_frame + 1.0 / k) + (1e-5 * np.abs(ref_mean)) ** 2)
+    if own_se:
+        # SURVEY 8(c)(iii) read literally: every side brings its own standard error — the reference the one of its samples
+        # (the fixture's), the GPU the spread of its K frames
+        den = np.sqrt(s ** 2 / k + np.asarray(ref_se, dtype=np.float64) ** 2 + (1e-5 * np.abs(ref_mean)) ** 2)
     z = (mean - ref_mean) / np.maximum(den, 1e-300)
     r = {"frac_z4": float(np.mean(np.abs(z) < PIXEL_Z)), "frac_z3": float(np.mean(np.abs(z) < 3.0)), "z_max": float(np.abs(z).max()),
          "z_mean": float(z.mean()), "z_std": float(z.std()),
@@ -65,5 +71,5 @@ def compare_frames(frames, ref_mean, ref_se=None, block=1):
     if ref_se is not None:      # same estimator, same spread: the reference's standard error against the frames'
         ref_se = np.asarray(ref_se, dtype=np.float64)
         ok = (ref_se > 0) & (s > 0)
-        r["median_se_ratio"] = float(np.median(s[ok] / ref_se[ok]))
+        r["median_se_ratio"] = float(np.median(s[ok] / (ref_se[ok] * np.sqrt(ref_samples_per_frame))))
     return r

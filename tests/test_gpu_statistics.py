@@ -24,6 +24,8 @@ import make_stat_golden as mg  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 FIXTURES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stat_fixtures.npz")
+# the two ratio-tracking cases again at 65 536 spp (make_stat_golden.py --ratio-deep): enough samples for the central limit theorem
+DEEP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stat_fixtures_ratio_deep.npz")
 RATIO, DELTA = 2, 3
 FRAMES = 64          # frames of 4096 spp per case: the per-pixel variance estimate has 63 degrees of freedom
 
@@ -57,16 +59,24 @@ def test_fast_mode_meets_the_per_pixel_bar_against_the_reference_scheme(backend,
     else:
         # A ratio-tracking sample is heavy-tailed: next-event estimation through a phase function with g = 0.924 under a
         # light of 1024 puts single samples at hundreds of times the pixel mean, and 4096 of them are too few for the
-        # REFERENCE's pixel mean to be normal.  Measured here: 0.2-1.1 % of the pixel-channels lie beyond 4 sigma, every one
-        # of them with the reference ABOVE the GPU's 262 144-sample mean (it caught a spike), the frames' spread is 1.1-1.4
-        # times what the reference's 4096 samples estimate (a variance estimate that misses the spikes), and the oracle's
-        # own two random schemes, compared the same one-sided way, behave the same.  So: the one-sidedness
-        # itself is asserted, the per-pixel fraction at the measured level, and the full bar on 8x8-pixel blocks, whose
-        # 262 144 reference samples are enough for the central limit theorem.
+        # REFERENCE's pixel mean to be normal: against the 4096-spp fixture 0.2-1.1 % of the pixel-channels lie beyond 4 sigma,
+        # every one of them with the reference ABOVE the GPU's 262 144-sample mean (it caught a spike).  That one-sidedness is
+        # asserted here as the explanation; the bar itself is asserted as SURVEY 8(c)(iii) writes it against the same oracle
+        # run 16 times longer (65 536 spp, tests/golden/stat_fixtures_ratio_deep.npz).
         z = (frames.mean(axis=0) - fx[name + "_mean"]) / np.maximum(frames.std(axis=0, ddof=1) * math.sqrt(1 + 1 / FRAMES), 1e-30)
         out = np.abs(z) > sc.PIXEL_Z
-        assert r["frac_z4"] >= 0.985, r
         assert np.sum(z[out] < 0) >= 0.98 * np.sum(out), (int(np.sum(out)), int(np.sum(z[out] < 0)))
+        deep = np.load(DEEP)
+        assert int(deep["spp"]) == 65536
+        # each side with its own standard error: the fixture's (65 536 samples: the estimate sees the spikes its mean caught)
+        # and the spread of the GPU's 64 frames
+        rd = sc.compare_frames(frames, deep[name + "_mean"], deep[name + "_stderr"], ref_samples_per_frame=16.0, own_se=True)
+        print(name, "against the 65 536-spp reference fixture:", rd)
+        assert rd["frac_z4"] >= sc.PIXEL_FRACTION and rd["image_mean_rel"] <= sc.IMAGE_MEAN_REL, rd
+        # (normalised by the frames' spread alone — as if 64 frames of 4096 samples knew the variance of a heavy-tailed pixel —
+        # the same comparison is at 99.89 % shipped / 96.3 % textbook with z up to 128: printed, not asserted)
+        rs = sc.compare_frames(frames, deep[name + "_mean"], deep[name + "_stderr"], ref_samples_per_frame=16.0)
+        print(name, "  ... normalised by the frames' spread alone:", rs)
         rb = sc.compare_frames(frames, fx[name + "_mean"], fx[name + "_stderr"], block=8)
         print(name, "8x8 blocks", rb)
         assert rb["frac_z4"] == 1.0 and rb["frac_z3"] >= 0.99, rb
