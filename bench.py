@@ -24,13 +24,20 @@ paths, and the next frame's waves fill it.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline      algorithmic density-lookup bytes (4 B per lookup, counted in-kernel) over the
-                HIP-event time of the integrator kernel, against the 8 TB/s HBM peak; inside it
-                "loads" = the same for the lookups that issued a load (4 B x voxel_loads: what the memory
-                system is asked for) and "valu" = wave-level VALU instructions per second against the issue
-                peak (1024 SIMDs x clock / 2) — what bounds the tracking kernels
+  roofline      of the integrator kernel, timed with HIP events on the backend's stream.  `bound` names what bounds it and
+                achieved / peak / frac are OF THAT BOUND, never above 1: "hbm" — algorithmic bytes (4 B per density lookup,
+                counted in-kernel) against 8 TB/s, where every lookup is a load; "valu" — VALU instructions per second
+                against the issue peak (1024 SIMDs x clock / 2), where sub-voxel steps serve most lookups from a register;
+                "hbm-latency" — HBM bytes (PMC) against 8 TB/s, where waves wait for random 4-byte gathers most of their
+                cycles.  Inside: `lookup_rate` = SURVEY 8(d)'s algorithmic figure (a rate), `loads` = 4 B x the lookups
+                that issued a load, `hbm` = traffic from the committed PMC passes (= `traffic`), `valu` = instruction rate,
+                lane utilisation, scalar instructions, share of wave cycles waiting (profiles/pmc_traffic.json)
   cpu_baseline  the CPU oracle (a port of the reference algorithm) on the host cores, on a
                 bounded sample of the same frame (N=1 only)
+
+--client group (single process, no torch.distributed): the frame over GPUs 0..N-1 through vr_group_render, the client
+behind the C-ABI that INTEGRATION.md 6 recommends (BaseIntegrator.cpp:143-181 replaced in one call); VR_BENCH_GROUP_DEVICES
+"0,0,0,0" lists the devices explicitly (a rehearsal on one GPU: never a measurement of scaling).
 """
 import argparse
 import json
@@ -89,6 +96,8 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"], help="see the module docstring")
     ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
                     help="also measure the K frames with two in flight (extra object; auto: tracking workloads, not in rehearsal)")
+    ap.add_argument("--client", default="ranks", choices=["ranks", "group"],
+                    help="ranks: one process per GPU, RCCL all_gather (the driver's launch); group: ONE process, vr_group_render over --gpus devices")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU work for the baseline sample")
     return ap.parse_args()
@@ -155,8 +164,66 @@ def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None):
     }
 
 
+def main_group(a):
+    """--client group: K frames through vr_group_render, each complete in (pageable) host memory when the call returns."""
+    from volume_renderer_amd import MODE_EXACT, MODE_FAST, MODE_FAST_LOCAL, BackendGroup, INTEGRATORS
+    from volume_renderer_amd import workloads as scenes
+    integ, n, W, H, spp, regime = WORKLOADS[a.workload]
+    if a.spp:
+        spp = a.spp
+    integ_id = INTEGRATORS[integ]
+    devs = [int(x) for x in os.environ.get("VR_BENCH_GROUP_DEVICES", ",".join(str(i) for i in range(a.gpus))).split(",")]
+    rehearsal = len(set(devs)) != len(devs)
+    g = BackendGroup(devs)
+    g.set_mode({"exact": MODE_EXACT, "local": MODE_FAST_LOCAL}.get(a.mode, MODE_FAST))
+    g.set_seed(scenes.SEED)
+    if regime == "mesh":
+        opts = scenes.options_marcher(W, H, spp)
+        if n == "cornell_sphere":
+            mesh = scenes.reference_model(n, os.path.join(ROOT, "tests", "golden", "ref_models.npz"))
+            opts.cameraPosition[:] = (0.0, 0.8, 3.6)
+            opts.fov = 40.0
+        else:
+            mesh = scenes.cube_mesh() if n == "cube" else scenes.icosphere_mesh()
+        g.set_mesh(mesh)
+    else:
+        g.generate_cloud(n, scenes.cloud_radius(n))
+        if integ.startswith("mesh"):
+            opts = scenes.options_mesh_tracker(integ, n, W, H, spp, regime=regime)
+            g.set_density_map(*scenes.mesh_tracker_grid_map(n))
+            g.set_mesh(scenes.icosphere_mesh())
+        else:
+            opts = scenes.options_cloud(integ, n, W, H, spp, regime=regime)
+    frame = np.zeros((H, W, 3), dtype=np.float32)            # pageable, like the reference's `new Vec3f[width * height]`
+    for _ in range(a.warmup):
+        g.render(opts, integ_id, out=frame)
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(a.steps):
+        g.render(opts, integ_id, out=frame)
+        kernel_ms += g.last_stats()["kernel_ms"]
+    dt = time.perf_counter() - t0
+    info = g.gather_info()
+    out = {"metric": "Mpath-samples/sec at 1080p (1/2/4/8 GPU) + density lookups/s vs HBM roofline",
+           "value": W * H * spp * a.steps / dt / 1e6, "unit": "Mpath-samples/s", "n_gpus": len(devs), "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": a.workload, "integrator": integ, "image": f"{W}x{H}", "spp": spp, "kernel_mode": a.mode,
+                      "partition": ("REHEARSAL: a GPU listed several times; " if rehearsal else "") +
+                                   f"one process, vr_group_render over devices {devs}, rows i::{len(devs)}, gather by 2-D copies into the caller's frame",
+                      "timed_span": "vr_group_render: render on every device + gather into host memory",
+                      "frame_mean_rgb": [float(x) for x in frame.mean(axis=(0, 1))]},
+           "group": {"slowest_device_kernel_ms_per_step": kernel_ms / a.steps, "gather_and_launch_ms_per_step": (dt * 1e3 - kernel_ms) / a.steps, **info}}
+    print(json.dumps(out), flush=True)
+    g.close()
+
+
 def main():
     a = parse()
+    if a.client == "group":
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("--client group runs in ONE process (no torch.distributed launcher)")
+        return main_group(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -353,33 +420,68 @@ def main():
                        5: "vr_gridmarch_kernel"}.get(integ_id, "vr_track_kernel")
         if a.mode == "local" and integ == "deltaTracking":
             kernel_name = "vr_delta_dda_kernel"
-        roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-            "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S, "traffic": traffic,
-            "kernel": kernel_name, "kernel_ms_per_launch": avg_launch_s * 1e3, "launches": int(launches_all),
-            "algorithmic_bytes_per_launch": bytes_per_launch,
-            "note": ("algorithmic bytes = 36 B (one BVH node) x closest-hit queries: a lower bound, the BVH is L2-resident"
-                     if mesh_scene else
-                     "algorithmic bytes = 4 B x in-kernel lookup count (one per step, as the reference makes them); steps that stay "
-                     "in a voxel are served from a register and empty-space runs are taken arithmetically, so frac measures "
-                     "lookup rate; 'loads' is what the memory system is asked for, 'traffic' what HBM delivered (PMC, "
-                     "committed profile), 'valu' the bound the counters point to"),
-        }
+        peak_gbs = HBM_PEAK_BYTES_PER_S / 1e9
+        # SURVEY 8(d)'s figure — 4 B x lookups as the reference makes them (36 B x closest-hit queries for the mesh marchers) over
+        # the kernel time — is a lookup RATE wherever the kernel serves lookups without memory (a step that stays in its voxel reads
+        # a register, empty-space and closed-form runs are arithmetic): kept as `lookup_rate`, never as a fraction of a roofline.
+        lookup_rate = {"bytes_per_launch": bytes_per_launch, "GBps": achieved, "x_hbm_peak": achieved / peak_gbs,
+                       "what": ("36 B (one BVH node) x closest-hit queries: a lower bound on what a query reads, and the BVH is cache-resident"
+                                if mesh_scene else "4 B x density lookups counted as the reference makes them (one per step of every walk)")}
+        loads_obj = None
+        loads_per_lookup = 1.0
         if not mesh_scene:
             loaded = loads_all * BYTES_PER_LOOKUP / nl
-            roofline["loads"] = {"bound": "hbm", "achieved": loaded / avg_launch_s / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-                                 "frac": loaded / avg_launch_s / HBM_PEAK_BYTES_PER_S, "bytes_per_launch": loaded,
-                                 "loads_per_lookup": loads_all / max(lookups_all, 1.0)}
+            loads_per_lookup = loads_all / max(lookups_all, 1.0)
+            loads_obj = {"achieved": loaded / avg_launch_s / 1e9, "peak": peak_gbs, "unit": "GB/s", "frac": loaded / avg_launch_s / HBM_PEAK_BYTES_PER_S,
+                         "bytes_per_launch": loaded, "loads_per_lookup": loads_per_lookup,
+                         "what": "4 B x the lookups that issued a load (counted in the kernel): what the memory system is asked for"}
+        hbm_obj = None
+        if traffic:
+            hbm_obj = {"achieved": traffic / avg_launch_s / 1e9, "peak": peak_gbs, "unit": "GB/s", "frac": traffic / avg_launch_s / HBM_PEAK_BYTES_PER_S,
+                       "bytes_per_launch": traffic, "source": pmc.get("source"),
+                       "what": "HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, in KiB) over the live kernel time"}
+        valu_obj = None
         if use_pmc and pmc.get("valu_insts_per_launch"):
             rate = pmc["valu_insts_per_launch"] / avg_launch_s
-            roofline["valu"] = {"bound": "valu", "achieved": rate / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "unit": "G wave-instr/s",
-                                "frac": rate / VALU_PEAK_WAVE_INSTS_PER_S, "insts_per_launch": pmc["valu_insts_per_launch"],
-                                "source": pmc.get("valu_source"),
-                                "note": "peak = one VALU instruction per 2 cycles per SIMD (nominal); compares, conversions, min/max and "
-                                        "three-input bit ops issue at half that rate and log/exp/rcp at a quarter (profiles/r02_ubench_valu.txt), "
-                                        "so a tracking kernel's mix saturates its SIMDs near frac 0.55"}
-            if pmc.get("valu_lane_utilisation"):
-                roofline["valu"]["lane_utilisation"] = pmc["valu_lane_utilisation"]   # SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)
+            valu_obj = {"achieved": rate / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "unit": "G wave-instr/s",
+                        "frac": rate / VALU_PEAK_WAVE_INSTS_PER_S, "insts_per_launch": pmc["valu_insts_per_launch"],
+                        "source": pmc.get("valu_source"),
+                        "note": "peak = one VALU instruction per 2 cycles per SIMD (nominal); compares, conversions, min/max and three-input bit ops "
+                                "issue at half that rate, log/exp/rcp at a quarter (profiles/r02_ubench_valu.txt), and the CU's one scalar unit "
+                                "takes issue slots beside them (profiles/r03_ubench_salu.txt): a tracking kernel's mix saturates near frac 0.55"}
+            for k in ("valu_lane_utilisation", "salu_insts_per_launch", "wave_cycles_waiting"):
+                if pmc.get(k) is not None:
+                    valu_obj[k.replace("valu_", "")] = pmc[k]
+        # What bounds the kernel, and the fraction OF THAT BOUND (never above 1):
+        #  - every lookup a load (grid marchers) or BVH reads: the contract's form, algorithmic bytes against the HBM peak;
+        #  - else, with the committed counters of this workload: "hbm-latency" when the waves wait most of their cycles
+        #    (random 4-byte gathers from a grid no cache holds) — HBM traffic against the peak; "valu" otherwise — the
+        #    instruction rate against the issue peak;
+        #  - else (another sample count, N > 1): the loaded bytes against the HBM peak.
+        if mesh_scene or loads_per_lookup >= 0.5:
+            bound, r_ach, r_peak, r_unit = "hbm", achieved, peak_gbs, "GB/s"
+        elif hbm_obj and valu_obj:
+            waiting = pmc.get("wave_cycles_waiting")
+            if (waiting is not None and waiting >= 0.5) or valu_obj["frac"] < 0.45:
+                bound, r_ach, r_peak, r_unit = "hbm-latency", hbm_obj["achieved"], peak_gbs, "GB/s"
+            else:
+                bound, r_ach, r_peak, r_unit = "valu", valu_obj["achieved"], valu_obj["peak"], valu_obj["unit"]
+        else:
+            bound, r_ach, r_peak, r_unit = "hbm", loads_obj["achieved"], peak_gbs, "GB/s"
+        roofline = {
+            "bound": bound, "achieved": r_ach, "peak": r_peak, "unit": r_unit, "frac": r_ach / r_peak, "traffic": traffic,
+            "kernel": kernel_name, "kernel_ms_per_launch": avg_launch_s * 1e3, "launches": int(launches_all),
+            "algorithmic_bytes_per_launch": bytes_per_launch, "lookup_rate": lookup_rate,
+            "note": "frac is the fraction of the bound named in `bound`; `lookup_rate` is SURVEY 8(d)'s algorithmic figure (a rate, not a "
+                    "fraction, wherever lookups are served without memory), `loads` what the memory system is asked for, `hbm` what HBM "
+                    "delivered (committed PMC passes), `valu` the instruction rate (DESIGN.md 6)",
+        }
+        if loads_obj:
+            roofline["loads"] = loads_obj
+        if hbm_obj:
+            roofline["hbm"] = hbm_obj
+        if valu_obj:
+            roofline["valu"] = valu_obj
         out = {
             "metric": "Mpath-samples/sec at 1080p (1/2/4/8 GPU) + density lookups/s vs HBM roofline",
             "value": value,

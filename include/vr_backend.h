@@ -189,15 +189,17 @@ int vr_group_set_mesh(vr_backend_group* g, const vr_mesh_desc* mesh);
 int vr_group_set_mode(vr_backend_group* g, int vr_mode);
 int vr_group_set_seed(vr_backend_group* g, uint64_t philox_key);
 /* BaseIntegrator::render up to :192 over all devices of the group; framebuffer_rgb = width*height*3
- * floats of HOST memory (pageable is fine: it is page-locked for the duration of the call so that the devices' copies
- * run as DMA side by side).  Returns after every device's rows have arrived — also on failure: nothing is in flight
+ * floats of HOST memory (pageable is fine: it is page-locked for the duration of the call, or the rows travel
+ * through a pinned staging buffer of the group, so that the devices' copies run as DMA side by side).  Returns after every device's rows have arrived — also on failure: nothing is in flight
  * when the call returns. */
 int vr_group_render(vr_backend_group* g, const vr_options_pod* o, int integrator, float* framebuffer_rgb);
 /* The same with the frame gathered in HBM: d_rgb = width*height*3 floats on the group's first GPU. */
 int vr_group_render_device(vr_backend_group* g, const vr_options_pod* o, int integrator, void* d_rgb);
 /* How the last gathers went, for diagnosing a slow one: out[0] / out[1] = devices (other than the first) with / without
- * peer access to the group's first GPU (without it vr_group_render_device's copies go through the host), out[2] = 1 when
- * the last vr_group_render could page-lock the caller's framebuffer for its copies (else they were staged). */
+ * peer access to the group's first GPU (without it vr_group_render_device's copies go through the host), out[2] = the way
+ * the last vr_group_render reached the caller's framebuffer: 1 = page-locked for the call (asynchronous copies straight
+ * to the rows' places), 2 = through the group's own pinned staging buffer (asynchronous copies, then a host memcpy per
+ * device as it finishes; taken where the platform refuses hipHostRegister), 0 = strided copies into pageable memory. */
 int vr_group_gather_info(const vr_backend_group* g, uint32_t out[3]);
 /* Counters summed over the devices; kernel_ms = the slowest device's integrator kernel time (the
  * devices run side by side), kernel_launches = the sum. */

@@ -54,9 +54,16 @@ for f in sorted(glob.glob(os.path.join(G, "*_sq.csv"))):
                     "loads_bytes_per_launch": bench["roofline"].get("loads", {}).get("bytes_per_launch")}
     out[key] = e
     name = workload if mode == "fast" else f"{workload}:{mode}"
+    sq = e["sq"]["counters_per_launch"]
     traffic[name] = {"hbm_bytes_per_launch": e["derived"]["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc_workloads.json",
                      "valu_insts_per_launch": e["derived"]["valu_insts_per_launch"],
-                     "valu_source": f"SQ_INSTS_VALU, profiles/{tag}_pmc_workloads.json"}
+                     "valu_source": f"SQ_INSTS_VALU, profiles/{tag}_pmc_workloads.json",
+                     "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"), "l2_hit_rate": e["derived"]["l2_hit_rate"]}
+    if sq.get("SQ_THREAD_CYCLES_VALU") and sq.get("SQ_ACTIVE_INST_VALU"):
+        traffic[name]["valu_lane_utilisation"] = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"] / 64.0
+    if sq.get("SQ_WAIT_ANY") and sq.get("SQ_WAVE_CYCLES"):
+        traffic[name]["wave_cycles_waiting"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+    e["derived"].update({k: traffic[name].get(k) for k in ("valu_lane_utilisation", "wave_cycles_waiting", "salu_insts_per_launch")})
     d = e["derived"]
     print(f"{key}: HBM {d['hbm_bytes_per_launch'] / 1e9:.1f} GB per launch = {d['hbm_GBps']:.0f} GB/s, L2 hit rate {d['l2_hit_rate']:.3f}, "
           f"VALU {d['valu_insts_per_launch']:.3g} per launch, loaded bytes {d['loads_bytes_per_launch']}")

@@ -63,6 +63,9 @@ if "prof_sq" in out and "SQ_INSTS_VALU" in out["prof_sq"]["counters_sum_over_lau
     traffic[workload]["valu_insts_per_launch"] = sq["counters_sum_over_launches"]["SQ_INSTS_VALU"] / sq["launches"]
     traffic[workload]["valu_source"] = f"SQ_INSTS_VALU, profiles/{tag}_bench_pmc_track_kernel.json"
     c = sq["counters_sum_over_launches"]
+    traffic[workload]["salu_insts_per_launch"] = c.get("SQ_INSTS_SALU", 0.0) / sq["launches"]
+    if c.get("SQ_WAIT_ANY") and c.get("SQ_WAVE_CYCLES"):
+        traffic[workload]["wave_cycles_waiting"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
     if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
         # lanes active per VALU instruction, of 64: what divergence (event phases, the per-trip service blocks) leaves
         traffic[workload]["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"] / 64.0

@@ -331,10 +331,11 @@ class BackendGroup:
         return fb
 
     def gather_info(self):
-        """{"peers_enabled", "peers_refused", "frame_registered"} of the last gathers (vr_group_gather_info)."""
+        """{"peers_enabled", "peers_refused", "frame_path"} of the last gathers (vr_group_gather_info); frame_path: "registered",
+        "staged" (pinned staging buffer) or "pageable"."""
         a = (C.c_uint32 * 3)()
         self._check(self._L.vr_group_gather_info(self._h, a))
-        return {"peers_enabled": int(a[0]), "peers_refused": int(a[1]), "frame_registered": bool(a[2])}
+        return {"peers_enabled": int(a[0]), "peers_refused": int(a[1]), "frame_path": {0: "pageable", 1: "registered", 2: "staged"}.get(int(a[2]), str(int(a[2])))}
 
     def render_device(self, opts, integrator, device_ptr):
         """The same with the frame gathered at device_ptr (height*width*3 floats) on the group's first GPU."""

@@ -1315,7 +1315,10 @@ struct vr_backend_group {
     std::vector<vr_backend*> dev;
     std::string              err;
     bool                     rendered = false;
-    bool                     frame_registered = false;   // the last vr_group_render page-locked the caller's frame
+    int                      frame_path = 0;             // how the last vr_group_render reached the caller's frame: 0 = copies into pageable memory,
+                                                         // 1 = the frame page-locked for the call, 2 = through the group's pinned staging buffer
+    float*                   h_stage = nullptr;          // pinned host memory (hipHostMalloc), one contiguous row block per device
+    size_t                   h_stage_cap = 0;            // in floats
     uint32_t                 peers_enabled = 0, peers_refused = 0;   // of the devices other than the first: peer access to the first GPU
 };
 
@@ -1363,15 +1366,33 @@ int group_render(vr_backend_group* g, const vr_options_pod* o, int integrator, f
         if (rc) return group_fail(g, rc, i, b);
     }
     const size_t row_bytes = (size_t)W * 3 * sizeof(float);
-    bool registered = false;
+    // the way to the caller's host frame: page-lock it for the call; where the platform refuses that (hipHostRegister returns
+    // "invalid argument" for any host pointer on some boxes), every device copies its row block — contiguous, asynchronous,
+    // side by side — into the group's pinned staging buffer and the host moves the rows to their places as each device
+    // finishes; the last resort is the strided copy into pageable memory
+    bool registered = false, staged = false;
+    std::vector<size_t> stage_off(N, 0);
     if (!frame_on_device && H && W) {
         const char* off = getenv("VR_GROUP_NO_REGISTER");
-        if (!(off && off[0] == '1')) {
+        const bool  plain = off && off[0] == '1';
+        if (!plain) {
             registered = hipHostRegister(frame, (size_t)H * row_bytes, hipHostRegisterDefault) == hipSuccess;
             if (!registered) (void)hipGetLastError();
         }
+        if (!registered && !plain) {
+            const size_t need = (size_t)H * W * 3;
+            if (g->h_stage_cap < need) {
+                if (g->h_stage) (void)hipHostFree(g->h_stage);
+                g->h_stage = nullptr; g->h_stage_cap = 0;
+                if (hipHostMalloc((void**)&g->h_stage, need * sizeof(float), hipHostMallocDefault) == hipSuccess) g->h_stage_cap = need;
+                else { g->h_stage = nullptr; (void)hipGetLastError(); }
+            }
+            staged = g->h_stage != nullptr;
+            size_t o2 = 0;
+            for (uint32_t i = 0; i < N; ++i) { stage_off[i] = o2; o2 += (size_t)count[i] * W * 3; }
+        }
     }
-    g->frame_registered = registered;
+    g->frame_path = registered ? 1 : (staged ? 2 : 0);
     int      first_rc = VR_OK;
     uint32_t launched = 0;                      // devices [0, launched) have work queued
     for (uint32_t i = 0; i < N && !first_rc; ++i) {
@@ -1388,8 +1409,10 @@ int group_render(vr_backend_group* g, const vr_options_pod* o, int integrator, f
         if (!count[i]) continue;
         int rc = use_device(b);
         if (rc) { first_rc = group_fail(g, rc, i, b); break; }
-        const hipError_t e = hipMemcpy2DAsync((char*)frame + (size_t)i * row_bytes, (size_t)N * row_bytes, b->d_rows, row_bytes, row_bytes,
-                                              count[i], frame_on_device ? hipMemcpyDefault : hipMemcpyDeviceToHost, b->stream);
+        const hipError_t e = staged
+            ? hipMemcpyAsync(g->h_stage + stage_off[i], b->d_rows, (size_t)count[i] * row_bytes, hipMemcpyDeviceToHost, b->stream)
+            : hipMemcpy2DAsync((char*)frame + (size_t)i * row_bytes, (size_t)N * row_bytes, b->d_rows, row_bytes, row_bytes,
+                               count[i], frame_on_device ? hipMemcpyDefault : hipMemcpyDeviceToHost, b->stream);
         if (e != hipSuccess) {
             fail(b, VR_ERR_HIP, "gather of the row block: %s", hipGetErrorString(e));
             first_rc = group_fail(g, VR_ERR_HIP, i, b);
@@ -1400,6 +1423,11 @@ int group_render(vr_backend_group* g, const vr_options_pod* o, int integrator, f
         int rc = use_device(b);
         if (!rc) rc = count[i] ? collect(b) : VR_OK;
         if (rc && !first_rc) first_rc = group_fail(g, rc, i, b);
+        if (staged && !first_rc && count[i]) {
+            const float* src = g->h_stage + stage_off[i];
+            for (uint32_t k = 0; k < count[i]; ++k)
+                memcpy((char*)frame + ((size_t)i + (size_t)k * N) * row_bytes, (const char*)src + (size_t)k * row_bytes, row_bytes);
+        }
     }
     if (registered && hipHostUnregister(frame) != hipSuccess) (void)hipGetLastError();
     g->rendered = first_rc == VR_OK;
@@ -1450,6 +1478,7 @@ int vr_group_create(const int* ordinals, uint32_t ndevices, vr_backend_group** o
 void vr_group_destroy(vr_backend_group* g)
 {
     if (!g) return;
+    if (g->h_stage) (void)hipHostFree(g->h_stage);
     for (vr_backend* b : g->dev) vr_backend_destroy(b);
     delete g;
 }
@@ -1477,7 +1506,7 @@ int vr_group_render_device(vr_backend_group* g, const vr_options_pod* o, int int
 int vr_group_gather_info(const vr_backend_group* g, uint32_t out[3])
 {
     if (!g || !out) return VR_ERR_INVALID_ARG;
-    out[0] = g->peers_enabled; out[1] = g->peers_refused; out[2] = g->frame_registered ? 1u : 0u;
+    out[0] = g->peers_enabled; out[1] = g->peers_refused; out[2] = (uint32_t)g->frame_path;
     return VR_OK;
 }
 
