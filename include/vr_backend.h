@@ -126,8 +126,10 @@ int vr_backend_render_row_set_device(vr_backend* b, const vr_options_pod* o, int
 int vr_backend_synchronize(vr_backend* b);
 
 /* vr_backend_render_row_set_device for callers that cannot allocate.  NO COUNTERPART IN THE
- * REFERENCE: it exists for callers that cannot call hipMalloc — code under HIP graph capture,
- * tight serving loops, harnesses that forbid allocation.  Same arguments, same frame (bit for bit)
+ * REFERENCE: it exists for callers that cannot call hipMalloc — tight serving loops, harnesses
+ * that forbid allocation, code that must not disturb a stream capture elsewhere (the call itself
+ * has not been exercised UNDER capture: it reads back nothing, but its launches go to the
+ * backend's own stream).  Same arguments, same frame (bit for bit)
  * and same asynchrony as vr_backend_render_row_set_device, but the call allocates and frees
  * nothing, creates no event and copies nothing from host memory: work counters, statistics
  * counters, the trackers' parameter block, the sub-sample offsets and the per-sample staging

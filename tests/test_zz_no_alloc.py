@@ -59,7 +59,8 @@ def test_noalloc_matches_allocating_entry_point_two_calls_in_a_row(backend, clou
     backend.set_mesh(scenes.icosphere_mesh())
     backend.set_seed(scenes.SEED)
     # first call large, second smaller (fewer pixels, fewer sub-samples, another row set): per kernel family
-    for integ, mode, regime in ((RATIO, MODE_EXACT_SKIP, "shipped"), (DELTA, MODE_FAST, "textbook"), (VDB_SIMPLE, MODE_FAST, "shipped")):
+    for integ, mode, regime in ((RATIO, MODE_EXACT_SKIP, "shipped"), (DELTA, MODE_FAST, "textbook"), (VDB_SIMPLE, MODE_FAST, "shipped"),
+                                (RATIO, MODE_FAST, "shipped"), (DELTA, MODE_FAST, "shipped")):     # (the last: closed-form voxel runs, GEOM)
         backend.set_mode(mode)
         big = scenes.options_cloud(integ, 64, 83, 61, 16, regime=regime)
         small = scenes.options_cloud(integ, 64, 37, 29, 4, regime=regime)
@@ -90,6 +91,40 @@ def test_noalloc_matches_allocating_entry_point_two_calls_in_a_row(backend, clou
         assert bitexact(a, b) and ast == bst, (integ, "big")
         (a, ast), (b, bst) = both(backend, scenes.options_marcher(33, 21, 1), integ)
         assert bitexact(a, b) and ast == bst, (integ, "small")
+
+
+def test_noalloc_allocates_nothing(cloud64):
+    """What the name promises, measured: a fresh backend whose allocating path has never run renders through the
+    allocation-free entry point — tracking, local-majorant and marching kernels — and the device's free memory does not move
+    (hipMemGetInfo before and after; the allocating entry point, run afterwards on the same backend, does take memory)."""
+    import torch
+    with Backend(0) as b:
+        b.set_density(cloud64)
+        b.set_mesh(scenes.icosphere_mesh())
+        b.set_seed(scenes.SEED)
+        dev = torch.zeros((61, 83, 3), dtype=torch.float32, device="cuda:0")
+        big = torch.zeros((1080, 1920, 3), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        for integ, mode, o in ((RATIO, MODE_FAST, scenes.options_cloud(RATIO, 64, 83, 61, 16)),
+                               (DELTA, MODE_FAST_LOCAL, scenes.options_cloud(DELTA, 64, 83, 61, 16, regime="textbook")),
+                               (NEE, MODE_FAST, scenes.options_marcher(83, 61, 4))):
+            b.set_mode(mode)
+            b.render_row_set_device_noalloc(o, integ, 0, 1, 61, dev.data_ptr())
+            b.synchronize()
+            assert b.last_stats()["path_samples"] == 83 * 61 * o.rayPerPixelCount
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free0
+        # the same frame size through both: 1080p at 16 spp needs 398 MB of staging, which the allocating entry point takes from
+        # the device and the allocation-free one renders in passes through its static array
+        o = scenes.options_cloud(DELTA, 64, 1920, 1080, 16, regime="textbook")
+        b.set_mode(MODE_FAST)
+        b.render_row_set_device_noalloc(o, DELTA, 0, 1, 1080, big.data_ptr())
+        b.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free0
+        b.render_row_set_device(o, DELTA, 0, 1, 1080, big.data_ptr())
+        b.synchronize()
+        assert torch.cuda.mem_get_info()[0] <= free0 - 300 * 2**20   # the staging buffer of the allocating path
 
 
 def test_noalloc_renders_in_passes_when_the_staging_area_is_short(backend, cloud64):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # sweep of one VR_TUNE_* knob on the same box, one process per point (0 = built-in default)
-# usage: VAR=VR_TUNE_CHUNK W="workload spp" tools/ab_tune.sh 0 64 128 256
+# usage: VAR=VR_TUNE_CHUNK W="workload spp" tools/experiments/ab_tune.sh 0 64 128 256
 VAR=${VAR:-VR_TUNE_ROUND_MAX}
 W=${W:-"config2_ratio_1080p_64spp_cloud512 64"}
 read WL SPP <<< "$W"

@@ -2,7 +2,7 @@
 """GPU-box check of the GEOM kernel (closed-form voxel runs of the FAST delta tracker where every free path is clamped):
 frame against the oracle's step-by-step restatement of the same clock (VRO_RNG_PHILOX_GEOM)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib as ol, scenes
