@@ -453,21 +453,22 @@ def main():
                 if pmc.get(k) is not None:
                     valu_obj[k.replace("valu_", "")] = pmc[k]
         # What bounds the kernel, and the fraction OF THAT BOUND (never above 1):
-        #  - every lookup a load (grid marchers) or BVH reads: the contract's form, algorithmic bytes against the HBM peak;
-        #  - else, with the committed counters of this workload: "hbm-latency" when the waves wait most of their cycles
-        #    (random 4-byte gathers from a grid no cache holds) — HBM traffic against the peak; "valu" otherwise — the
-        #    instruction rate against the issue peak;
-        #  - else (another sample count, N > 1): the loaded bytes against the HBM peak.
+        #  - "hbm": the contract's form, algorithmic bytes against the HBM peak — a candidate where every lookup is a load
+        #    (grid marchers, voxel-sized steps) or a BVH read;
+        #  - with the committed counters of this workload, two more candidates: "hbm-latency" — the HBM traffic of random
+        #    4-byte gathers (each drags a 128-byte line in) against the peak — and "valu" — the instruction rate against the
+        #    issue peak;
+        #  - without counters (another sample count, N > 1) and lookups served from registers: the loaded bytes against the HBM peak.
+        #  With counters the named bound is the one the kernel sits closest to (the largest of the candidate fractions).
+        cands = []
         if mesh_scene or loads_per_lookup >= 0.5:
-            bound, r_ach, r_peak, r_unit = "hbm", achieved, peak_gbs, "GB/s"
-        elif hbm_obj and valu_obj:
-            waiting = pmc.get("wave_cycles_waiting")
-            if (waiting is not None and waiting >= 0.5) or valu_obj["frac"] < 0.45:
-                bound, r_ach, r_peak, r_unit = "hbm-latency", hbm_obj["achieved"], peak_gbs, "GB/s"
-            else:
-                bound, r_ach, r_peak, r_unit = "valu", valu_obj["achieved"], valu_obj["peak"], valu_obj["unit"]
-        else:
-            bound, r_ach, r_peak, r_unit = "hbm", loads_obj["achieved"], peak_gbs, "GB/s"
+            cands.append(("hbm", achieved, peak_gbs, "GB/s"))
+        if hbm_obj and valu_obj:
+            cands.append(("hbm-latency", hbm_obj["achieved"], peak_gbs, "GB/s"))
+            cands.append(("valu", valu_obj["achieved"], valu_obj["peak"], valu_obj["unit"]))
+        if not cands:
+            cands.append(("hbm", loads_obj["achieved"], peak_gbs, "GB/s"))
+        bound, r_ach, r_peak, r_unit = max(cands, key=lambda c: c[1] / c[2])
         roofline = {
             "bound": bound, "achieved": r_ach, "peak": r_peak, "unit": r_unit, "frac": r_ach / r_peak, "traffic": traffic,
             "kernel": kernel_name, "kernel_ms_per_launch": avg_launch_s * 1e3, "launches": int(launches_all),
