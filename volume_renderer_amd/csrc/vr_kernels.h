@@ -266,6 +266,9 @@ __device__ __forceinline__ int closest_hit_march(const MeshDev& m, f3 org, f3 di
 // inside a medium (scattered rays, shadow rays) starts with that medium's object as "the last one".  Opaque shapes
 // (dissolve <= 0) are black absorbers.  [s0, s1] is in units of |dir| from org.  (oracle: mesh_segment)
 enum { SEG_NONE = 0, SEG_FOUND = 1, SEG_BLACK = 2 };
+#ifndef VR_MESH_TRACK_WAVE_BVH
+#define VR_MESH_TRACK_WAVE_BVH 0
+#endif
 __device__ __forceinline__ int mesh_segment(const MeshDev& m, f3 org, f3 dir, int inside_id, float& s0, float& s1, int& medium, uint32_t& n_queries)
 {
     int   object = inside_id;
@@ -273,7 +276,7 @@ __device__ __forceinline__ int mesh_segment(const MeshDev& m, f3 org, f3 dir, in
     for (int guard = 0; guard < 64; ++guard) {
         float t;
         n_queries++;
-        const int prim = closest_hit(m, org, dir, t);
+        const int prim = VR_MESH_TRACK_WAVE_BVH ? closest_hit_wave(m, org, dir, t) : closest_hit(m, org, dir, t);
         if (prim < 0) return SEG_NONE;
         const int previous = object;
         object = (int)m.prim_to_shape[prim];
