@@ -1472,8 +1472,21 @@ struct MarchParams {
 // KIND: which handleIntersection marches the segment between entry and exit hit
 enum { MARCH_NEE = 0, MARCH_IMPROVED = 1, MARCH_PERLIN = 2, MARCH_DENSITY = 3 };
 
+// Waves per SIMD the register allocator must allow for the marchers (0 = whatever the kernel needs: 86-130 VGPRs, five to
+// three waves).  With the wave-uniform BVH walk a query is a chain of scalar fetch -> slab test -> next node, and what
+// hides the fetch is other waves: seven per SIMD (72 VGPRs, 60-170 bytes of scratch outside the walk) measured against
+// the natural allocation on config 5 — sphere 90.6 -> 79.1 ms (Improved) and 85.6 -> 67.9 (NEE), CornellBox-Sphere
+// 50.7 -> 47.6 and 47.3 -> 41.6, Perlin marcher 15.5 -> 12.7; six and eight are 2-9 % behind seven.  (Before that walk
+// the kernel was bound by the L1 request path and forced occupancy bought nothing: DESIGN.md 6b.)
+#ifndef VR_MARCH_WAVES
+#define VR_MARCH_WAVES 7
+#endif
 template <int KIND, bool EXACT>
-__global__ void __launch_bounds__(256) vr_march_kernel(const MarchParams p)
+__global__ void __launch_bounds__(256)
+#if VR_MARCH_WAVES
+__attribute__((amdgpu_waves_per_eu(VR_MARCH_WAVES, VR_MARCH_WAVES)))
+#endif
+vr_march_kernel(const MarchParams p)
 {
     typedef Math<EXACT> M;
     constexpr bool IMPROVED = KIND == MARCH_IMPROVED;
