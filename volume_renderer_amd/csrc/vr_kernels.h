@@ -1698,8 +1698,15 @@ struct GridMarchParams {
     float     light[3], light_color[3], emission[3], background[3];
 };
 
+#ifndef VR_GRIDMARCH_WAVES
+#define VR_GRIDMARCH_WAVES 0   // waves per SIMD the register allocator must allow (0: what the kernel needs, 73-78 VGPRs = six)
+#endif
 template <bool EMISSION, bool EXACT>
-__global__ void __launch_bounds__(256) vr_gridmarch_kernel(const GridMarchParams p)
+__global__ void __launch_bounds__(256)
+#if VR_GRIDMARCH_WAVES
+__attribute__((amdgpu_waves_per_eu(VR_GRIDMARCH_WAVES, VR_GRIDMARCH_WAVES)))
+#endif
+vr_gridmarch_kernel(const GridMarchParams p)
 {
     typedef Math<EXACT> M;
     const uint32_t k0 = p.work.key0, k1 = p.work.key1;
