@@ -81,7 +81,7 @@ WORKLOADS = {
     "config5_tracker_delta_sphere_4k": ("meshDeltaTracking", 1024, 3840, 2160, 256, "textbook"),
     "config5_tracker_delta_shipped_sphere_4k": ("meshDeltaTracking", 1024, 3840, 2160, 64, "shipped"),
 }
-BVH_NODE_BYTES = 36            # one BvhNode per closest-hit query at the least (vr_kernels.h)
+BVH_NODE_BYTES = 32            # one BvhNode per closest-hit query at the least (vr_kernels.h)
 
 
 def parse():
@@ -421,11 +421,11 @@ def main():
         if a.mode == "local" and integ == "deltaTracking":
             kernel_name = "vr_delta_dda_kernel"
         peak_gbs = HBM_PEAK_BYTES_PER_S / 1e9
-        # SURVEY 8(d)'s figure — 4 B x lookups as the reference makes them (36 B x closest-hit queries for the mesh marchers) over
+        # SURVEY 8(d)'s figure — 4 B x lookups as the reference makes them (32 B x closest-hit queries for the mesh marchers) over
         # the kernel time — is a lookup RATE wherever the kernel serves lookups without memory (a step that stays in its voxel reads
         # a register, empty-space and closed-form runs are arithmetic): kept as `lookup_rate`, never as a fraction of a roofline.
         lookup_rate = {"bytes_per_launch": bytes_per_launch, "GBps": achieved, "x_hbm_peak": achieved / peak_gbs,
-                       "what": ("36 B (one BVH node) x closest-hit queries: a lower bound on what a query reads, and the BVH is cache-resident"
+                       "what": ("32 B (one BVH node) x closest-hit queries: a lower bound on what a query reads, and the BVH is cache-resident"
                                 if mesh_scene else "4 B x density lookups counted as the reference makes them (one per step of every walk)")}
         loads_obj = None
         loads_per_lookup = 1.0

@@ -478,15 +478,14 @@ uint32_t build_bvh(std::vector<BuildTri>& t, uint32_t first, uint32_t count, std
     tree.push_back(tn);
     int axis = 0;
     for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-    if (count <= leaf_size || !(chi[axis] > clo[axis])) {
-        tree[me].box.first = (uint32_t)order.size();
-        tree[me].box.count = count;
+    if (count <= leaf_size || (!(chi[axis] > clo[axis]) && count <= 255u)) {   // (coincident centroids: one leaf, of at most 255 — the node's count has 8 bits)
+        tree[me].box.leaf = (count << 24) | (uint32_t)order.size();   // (set_mesh checks: < 2^24 triangles, leaves of < 256)
         for (uint32_t i = first; i < first + count; ++i) order.push_back(i);
     } else {
         const uint32_t mid = count / 2;
         std::nth_element(t.begin() + first, t.begin() + first + mid, t.begin() + first + count,
                          [axis](const BuildTri& x, const BuildTri& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.prim < y.prim); });
-        tree[me].box.first = 0; tree[me].box.count = 0;
+        tree[me].box.leaf = 0;
         tree[me].axis = axis;
         const uint32_t l = build_bvh(t, first, mid, tree, order, leaf_size);             // lower centroids along `axis`
         const uint32_t r = build_bvh(t, first + mid, count - mid, tree, order, leaf_size);
@@ -500,7 +499,7 @@ void thread_bvh(const std::vector<TreeNode>& tree, uint32_t n, int octant, std::
 {
     const size_t me = nodes.size();
     nodes.push_back(tree[n].box);
-    if (tree[n].box.count == 0) {
+    if (tree[n].box.leaf == 0) {
         const bool neg = (octant >> tree[n].axis) & 1;
         thread_bvh(tree, neg ? tree[n].right : tree[n].left, octant, nodes, base);
         thread_bvh(tree, neg ? tree[n].left : tree[n].right, octant, nodes, base);
@@ -1174,7 +1173,8 @@ int vr_backend_set_mesh(vr_backend* b, const vr_mesh_desc* m)
     std::vector<TreeNode> tree;
     std::vector<uint32_t> order;
     read_knobs(b);
-    build_bvh(bt, 0, m->ntris, tree, order, (uint32_t)(b->tune_bvh_leaf > 0 ? b->tune_bvh_leaf : 1));
+    if (m->ntris >= (1u << 24)) return fail(b, VR_ERR_INVALID_ARG, "%u triangles: a BVH leaf addresses 2^24", m->ntris);
+    build_bvh(bt, 0, m->ntris, tree, order, (uint32_t)std::min(b->tune_bvh_leaf > 0 ? b->tune_bvh_leaf : 1, 255));
     std::vector<BvhNode>  nodes;                         // 8 layouts of tree.size() nodes each
     for (int octant = 0; octant < 8; ++octant) thread_bvh(tree, 0, octant, nodes, nodes.size());
     std::vector<TriDev> tris(order.size());

@@ -108,11 +108,14 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 // for a leaf the next subtree), a node that is missed continues at `skip`.  No stack.  MeshDev::nodes
 // holds eight such layouts of the same tree, one per sign octant of the ray direction, each visiting
 // the child nearer to its rays first.
+// A node is 32 bytes — ONE aligned s_load_dwordx8 of the wave-uniform walk, never straddling a cache line.
 struct BvhNode {
     float    lo[3], hi[3];
     uint32_t skip;
-    uint32_t first, count;   // leaf: triangles [first, first+count); inner: count = 0
+    uint32_t leaf;           // leaf: count << 24 | first — triangles [first, first + count); inner: 0
 };
+#define VR_BVH_FIRST(leaf) ((leaf) & 0xffffffu)
+#define VR_BVH_COUNT(leaf) ((leaf) >> 24)
 struct TriDev {
     float    v0[3], e1[3], e2[3];
     uint32_t prim;    // original primitive id (tie-break + prim_to_shape index)
@@ -166,8 +169,8 @@ __device__ __forceinline__ int closest_hit(const MeshDev& m, f3 org, f3 dir, flo
         float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
         float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_t));
         if (tn <= tf) {
-            for (uint32_t k = 0; k < nd.count; ++k) {
-                const TriDev tr = m.tris[nd.first + k];
+            for (uint32_t k = 0; k < VR_BVH_COUNT(nd.leaf); ++k) {
+                const TriDev tr = m.tris[VR_BVH_FIRST(nd.leaf) + k];
                 float        t;
                 if (tri_hit(tr, org, dir, t) && (t < best_t || (t == best_t && tr.prim < best_prim))) {
                     best_t = t; best_prim = tr.prim;
@@ -207,17 +210,17 @@ __device__ __forceinline__ int closest_hit_wave(const MeshDev& m, f3 org, f3 dir
         const uint32_t uoct = (uint32_t)__builtin_amdgcn_readfirstlane((int)oct);
         if (oct == uoct) {
             pending = false;
-            const const_u32p nodes = as_constant(m.nodes) + (size_t)uoct * nn * 9u;
+            const const_u32p nodes = as_constant(m.nodes) + (size_t)uoct * nn * 8u;
             const const_u32p tris = as_constant(m.tris);
             uint32_t n = 0;          // wave-uniform
             uint32_t resume = 0;     // this lane takes part from node `resume` on
             // (Fetching node n + 1 — where the walk goes whenever some lane hits — beside node n was measured: 30 % SLOWER.
             // Scalar loads return out of order, so the first use of either waits for both.)
             while (n < nn) {
-                const const_u32p q = nodes + (size_t)n * 9u;
+                const const_u32p q = nodes + (size_t)n * 8u;
                 const float lo0 = __uint_as_float(q[0]), lo1 = __uint_as_float(q[1]), lo2 = __uint_as_float(q[2]);
                 const float hi0 = __uint_as_float(q[3]), hi1 = __uint_as_float(q[4]), hi2 = __uint_as_float(q[5]);
-                const uint32_t skip = q[6], first = q[7], count = q[8];
+                const uint32_t skip = q[6], first = VR_BVH_FIRST(q[7]), count = VR_BVH_COUNT(q[7]);
                 const bool act = n >= resume;
                 float ax = (lo0 - org.x) * ix, bx = (hi0 - org.x) * ix;
                 float ay = (lo1 - org.y) * iy, by = (hi1 - org.y) * iy;
