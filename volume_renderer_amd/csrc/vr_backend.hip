@@ -864,7 +864,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
             // and up to 96 trips (swept on config 5's tracker leg: ratio 129 -> 181 M samples/s, delta 450 -> 828 shipped,
             // 519 -> 1 010 textbook against the limits of the plain kernels).
             p.round_max = tuned(b->tune_round_max, (span && !mesh_bound) ? VR_ROUND_MAX : 2 * VR_ROUND_MAX);
-            p.round_events = tuned(b->tune_round_events, mesh_bound ? 4 * VR_ROUND_EVENTS : (span ? VR_ROUND_EVENTS : 2 * VR_ROUND_EVENTS));   // (the ratio tracker took 16 while a trip drew from the generator twice per iteration; 12 since: +1.5 %)
+            p.round_events = tuned(b->tune_round_events, mesh_bound ? (ratio ? 4 * VR_ROUND_EVENTS : 56) : (span ? VR_ROUND_EVENTS : 2 * VR_ROUND_EVENTS));   // (mesh-bounded delta tracking, re-swept with 32-byte nodes: 2073 / 1866 / 1720 / 1664 ms at 32 / 40 / 48 / 56 on config 5's textbook leg; the ratio leg is flat from 48 on)   // (the ratio tracker took 16 while a trip drew from the generator twice per iteration; 12 since: +1.5 %)
             void (*kern)(const TrackParams);
             // empty-space runs read the skip grid, whose empty voxels only keep the sign of sigma for
             // multipliers >= 0 (the shadow multiplier is only read by the ratio tracker)

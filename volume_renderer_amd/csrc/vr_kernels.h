@@ -231,7 +231,7 @@ __device__ __forceinline__ int closest_hit_wave(const MeshDev& m, f3 org, f3 dir
                 if (act && !hit) resume = skip;
                 if (__ballot(hit) != 0ull) {
                     for (uint32_t k = 0; k < count; ++k) {
-                        const const_u32p tq = tris + (size_t)(first + k) * 10u;
+                        const const_u32p tq = tris + (size_t)(first + k) * (sizeof(TriDev) / 4u);
                         TriDev tr;
                         tr.v0[0] = __uint_as_float(tq[0]); tr.v0[1] = __uint_as_float(tq[1]); tr.v0[2] = __uint_as_float(tq[2]);
                         tr.e1[0] = __uint_as_float(tq[3]); tr.e1[1] = __uint_as_float(tq[4]); tr.e1[2] = __uint_as_float(tq[5]);
