@@ -360,6 +360,33 @@ def test_marchers_exact_mode_is_bit_identical(backend, oracle, mesh_name, integ)
     assert 0.1 < np.mean(np.any(want != bg, axis=-1)) < 0.9   # the medium covers part of the frame
 
 
+def test_bvh_leaves_hold_coincident_triangles_and_any_leaf_size(backend, oracle, monkeypatch):
+    """The 32-byte BVH node packs a leaf's triangle count into 8 bits.  600 copies of one cube face (coincident centroids: no
+    split separates them) must end up in leaves of at most 255 and still give the oracle's brute-force frame; so must leaves
+    of 4 and of 300 (clamped to 255) triangles on the icosphere (VR_TUNE_BVH_LEAF)."""
+    cube = scenes.cube_mesh()
+    extra = np.repeat(cube.tris[:1], 600, axis=0)
+    from volume_renderer_amd.abi import Mesh
+    mesh = Mesh(cube.verts, np.concatenate([cube.tris, extra]), np.zeros(len(cube.tris) + 600, dtype=np.uint32), np.array([0.5], dtype=np.float32))
+    o = scenes.options_marcher(64, 64, 1)
+    sc, _ = ol.make_scene(mesh=mesh)
+    want, wst = oracle_image(oracle, sc, o, NEE)
+    backend.set_mode(MODE_EXACT)
+    backend.set_seed(scenes.SEED)
+    backend.set_mesh(mesh)
+    assert bitexact(backend.render(o, NEE), want)
+    assert backend.last_stats()["ray_queries"] == wst["ray_queries"]
+    ico = scenes.icosphere_mesh()
+    sc2, _ = ol.make_scene(mesh=ico)
+    want2, _ = oracle_image(oracle, sc2, o, IMPROVED)
+    for leaf in ("4", "300"):
+        monkeypatch.setenv("VR_TUNE_BVH_LEAF", leaf)
+        backend.set_mesh(ico)
+        assert bitexact(backend.render(o, IMPROVED), want2), leaf
+    monkeypatch.delenv("VR_TUNE_BVH_LEAF")
+    backend.set_mesh(ico)
+
+
 GOLDEN_MODELS = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "ref_models.npz")
 CORNELL_VIEW = dict(cameraPosition=(0.0, 0.8, 3.6), fov=40.0)       # looks into the box ([-1.02, 1] x [0, 1.59] x [-1.04, 0.99])
 
