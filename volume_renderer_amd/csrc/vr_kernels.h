@@ -365,6 +365,9 @@ enum {
 #ifndef VR_FLAT_ITER
 #define VR_FLAT_ITER 1
 #endif
+#ifndef VR_ONE_STREAM_EXP
+#define VR_ONE_STREAM_EXP 0   // timing experiment: FAST walks go on drawing from the path's first stream (no Philox per walk)
+#endif
 #define VR_ROUND_MAX 48      // step-loop trips before the event phase runs regardless
 #define VR_ROUND_EVENTS 12   // ... or as soon as this many lanes wait for it
 // Iterations of the reference's loop per trip.  A trip ends with ONE empty-space service and ONE voxel
@@ -650,7 +653,7 @@ vr_track_kernel(const TrackParams p)
                     st = ST_SHADOW_DONE;
                 } else {
                     shadow = true; Tsh = T_ONE; st = ST_WALK;
-                    seed_stream();
+                    if (!(VR_ONE_STREAM_EXP && !EXACT)) seed_stream();
                     set_ray(so, light, c0, c1);
                 }
             }
@@ -672,7 +675,7 @@ vr_track_kernel(const TrackParams p)
                 // the next bounce's stream starts with the direction sample
                 n_lookups += rng_step;
                 rng_ts += 1u << 20; rng_step = 0;
-                seed_stream();
+                if (!(VR_ONE_STREAM_EXP && !EXACT)) seed_stream();
                 uint32_t h0, h1;
                 xoshiro128p_next2(xs0, xs1, xs2, xs3, h0, h1);
                 const float xi1 = in_range(h0, 0.0f, 0.9999f);
