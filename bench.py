@@ -418,7 +418,7 @@ def main():
         traffic = pmc.get("hbm_bytes_per_launch") if use_pmc else None
         kernel_name = {0: "vr_march_kernel", 1: "vr_march_kernel", 6: "vr_march_kernel", 7: "vr_march_kernel", 4: "vr_gridmarch_kernel",
                        5: "vr_gridmarch_kernel"}.get(integ_id, "vr_track_kernel")
-        if a.mode == "local" and integ == "deltaTracking":
+        if a.mode == "local" and integ in ("deltaTracking", "meshDeltaTracking"):
             kernel_name = "vr_delta_dda_kernel"
         peak_gbs = HBM_PEAK_BYTES_PER_S / 1e9
         # SURVEY 8(d)'s figure — 4 B x lookups as the reference makes them (32 B x closest-hit queries for the mesh marchers) over

@@ -1154,7 +1154,9 @@ static float local_cell_value(const vr_grid_desc* g, v3 p, const local_dda* s)
     return g->voxels[((int64_t)v[0] * ny + v[1]) * nz + v[2]];
 }
 
-static v3 cast_ray_delta_local(path_ctx* d)
+/* mesh_bound (VRO_INTEGRATOR_MESH_DELTA_LOCAL, the estimator of meshDeltaTracking in the LOCAL modes): the walk's segments are cut
+ * to the mesh's entry/exit interval exactly where cast_ray_delta(d, 1) cuts them — no reference counterpart either way. */
+static v3 cast_ray_delta_local(path_ctx* d, int mesh_bound)
 {
     const vr_options_pod* o = d->o;
     const vr_grid_desc* grid = d->sc->density;
@@ -1165,7 +1167,16 @@ static v3 cast_ray_delta_local(path_ctx* d)
     int depthRemaining = (int)o->maxDepth;                                  /* REF :17 */
 
     iray iRay = ray_world_to_index(grid, d->rayOrigin, d->rayDirection);    /* REF :30-35 */
-    if (!ray_clip(&iRay, grid) || o->maxDepth == 0) return opt3(o->backgroundColor);   /* REF :37-39, :54 */
+    if (!ray_clip(&iRay, grid)) return opt3(o->backgroundColor);           /* REF :37-39 */
+    int medium = -1;
+    if (mesh_bound) {
+        v3 idir = mat_mult(grid->inv_mat, d->rayDirection);
+        float length = sqrtf(idir.x * idir.x + idir.y * idir.y + idir.z * idir.z);
+        int empty, rc = mesh_clip(d, &iRay, d->rayOrigin, d->rayDirection, length, -1, &medium, &empty);
+        if (rc == SEG_BLACK) return v3_make(0, 0, 0);
+        if (rc == SEG_NONE || empty) return opt3(o->backgroundColor);
+    }
+    if (o->maxDepth == 0) return opt3(o->backgroundColor);                  /* REF :54 */
 
     float t = iRay.t0;                                                      /* REF :50 */
     local_dda s;
@@ -1231,6 +1242,10 @@ static v3 cast_ray_delta_local(path_ctx* d)
         d->rayDirection = scattered;                                        /* REF :146 */
         iRay = ray_make(point, scattered, 1e-5f, FLT_MAX);                  /* REF :147 */
         if (!ray_clip(&iRay, grid)) return v3_make(0, 0, 0);                /* REF :150-155 "scattering failed" */
+        if (mesh_bound) {
+            int empty, rc = mesh_clip(d, &iRay, index_to_world(grid, point), mat_mult(grid->mat, scattered), 1.0f, medium, &medium, &empty);
+            if (rc == SEG_BLACK || empty) return v3_make(0, 0, 0);
+        }
         if (depthRemaining <= 0) return opt3(o->backgroundColor);           /* REF :54, :175 */
         t = iRay.t0;                                                        /* REF :157 */
         local_dda_start(&s, grid, &iRay, t, mu_scale);
@@ -1717,15 +1732,17 @@ static v3 cast_ray(path_ctx* d, int integrator)
     case VR_INTEGRATOR_NANOVDB_EMISSION:                 return cast_ray_grid_marcher(d, 1);
     case VR_INTEGRATOR_HETEROGENEOUS_PERLIN_NOISE:       return cast_ray_marcher(d, 2); /* same castRay walk (:12-60, :155-168) */
     case VR_INTEGRATOR_DENSITY_SAMPLING:                 return cast_ray_density_sampling(d);
-    case VRO_INTEGRATOR_DELTA_LOCAL:                     return cast_ray_delta_local(d);
+    case VRO_INTEGRATOR_DELTA_LOCAL:                     return cast_ray_delta_local(d, 0);
+    case VRO_INTEGRATOR_MESH_DELTA_LOCAL:                return cast_ray_delta_local(d, 1);
     default:                                             return cast_ray_delta(d, 0);
     }
 }
 
 static int scene_ok(const vro_scene* sc, int integrator)
 {
-    if (integrator == VRO_INTEGRATOR_DELTA_LOCAL) {
+    if (integrator == VRO_INTEGRATOR_DELTA_LOCAL || integrator == VRO_INTEGRATOR_MESH_DELTA_LOCAL) {
         if (!sc->density) return VR_ERR_NO_DENSITY;
+        if (integrator == VRO_INTEGRATOR_MESH_DELTA_LOCAL && !sc->mesh) return VR_ERR_NO_MESH;
         if (g_local.grid != sc->density || !g_local.major) return VR_ERR_INVALID_ARG;   /* vro_local_majorants_build first */
         return VR_OK;
     }

@@ -44,7 +44,7 @@ enum {
 
 /* Oracle-only integrator: delta tracking over per-cell majorants (the estimator of VR_MODE_FAST_LOCAL / VR_MODE_EXACT_LOCAL;
  * no reference counterpart — vr_oracle.c, cast_ray_delta_local).  vro_local_majorants_build(grid, cell_log) first. */
-enum { VRO_INTEGRATOR_DELTA_LOCAL = 100 };
+enum { VRO_INTEGRATOR_DELTA_LOCAL = 100, VRO_INTEGRATOR_MESH_DELTA_LOCAL = 101 /* the same bounded by the mesh (meshDeltaTracking in the LOCAL modes) */ };
 /* Study switches of the reference-faithful delta tracker (vr_oracle.c, cast_ray_delta); 0 = the reference as written */
 enum { VRO_DELTA_LOOKUP_AFTER_STEP = 1, VRO_DELTA_CLAMP_ENTRY = 2 };
 

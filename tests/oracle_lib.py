@@ -21,6 +21,7 @@ RNG_PHILOX_GEOM = 2             # RNG_PHILOX + the one-clock-per-walk draws of t
 MATH_LIBM = 0
 MATH_SHARED = 1
 DELTA_LOCAL = 100               # VRO_INTEGRATOR_DELTA_LOCAL: the oracle's restatement of VR_MODE_FAST_LOCAL / EXACT_LOCAL
+MESH_DELTA_LOCAL = 101          # VRO_INTEGRATOR_MESH_DELTA_LOCAL: the same bounded by the mesh
 DELTA_LOOKUP_AFTER_STEP = 1     # study switches of the reference-faithful delta tracker (vro_set_delta_variant)
 DELTA_CLAMP_ENTRY = 2
 

@@ -13,7 +13,7 @@ import pytest
 
 import oracle_lib as ol
 import scenes
-from volume_renderer_amd import MODE_EXACT, MODE_EXACT_SKIP, MODE_FAST, Backend, Grid
+from volume_renderer_amd import MODE_EXACT, MODE_EXACT_LOCAL, MODE_EXACT_SKIP, MODE_FAST, MODE_FAST_LOCAL, Backend, Grid
 
 pytestmark = pytest.mark.gpu
 
@@ -112,6 +112,46 @@ def test_mesh_trackers_fast_mode_tracks_the_oracle(backend, oracle, integ):
     assert abs(got.mean() - want.mean()) / want.mean() < 5e-3
     assert abs(st["density_lookups"] - wst["density_lookups"]) / wst["density_lookups"] < 5e-3
     assert abs(st["ray_queries"] - wst["ray_queries"]) / wst["ray_queries"] < 5e-3
+
+
+@pytest.mark.parametrize("name,level", [("cube", 0), ("icosphere", 1), ("two_objects", 0), ("sphere_only", 0), ("cornell_sphere", 1)])
+def test_mesh_delta_tracking_over_local_majorants_is_bit_identical_to_its_oracle(backend, oracle, monkeypatch, name, level):
+    """meshDeltaTracking in the LOCAL modes (vr_delta_dda_kernel<.., MESH>): the local-majorant delta tracker with every ray cut to
+    the mesh's entry/exit interval.  No reference counterpart twice over; the oracle restates it (cast_ray_delta_local with
+    mesh_bound) and the EXACT build must give its frame bit for bit — image, tentative collisions, scatters, closest-hit
+    queries; the production build walks the same streams."""
+    mesh, grid, kw = scene_case(oracle, name)
+    o = scenes.options_mesh_tracker(MESH_DELTA, 64, 56, 48, 4, regime="textbook", **kw)
+    sc, _ = ol.make_scene(density=grid, mesh=mesh)
+    ol.local_majorants(sc, 3 + level)
+    oracle.vro_set_math_mode(ol.MATH_SHARED)
+    try:
+        want, wst = ol.render(sc, o, ol.MESH_DELTA_LOCAL, rng_mode=ol.RNG_PHILOX, seed=scenes.SEED, want_stats=True)
+    finally:
+        oracle.vro_set_math_mode(ol.MATH_LIBM)
+        oracle.vro_local_majorants_free()
+    monkeypatch.setenv("VR_TUNE_MAJORANT_LEVEL", str(level))
+    backend.set_density(grid)
+    backend.set_mesh(mesh)
+    backend.set_seed(scenes.SEED)
+    backend.set_mode(MODE_EXACT_LOCAL)
+    got = backend.render(o, MESH_DELTA)
+    st = backend.last_stats()
+    assert bitexact(got, want), f"{np.count_nonzero(got.view(np.uint32) != want.view(np.uint32))} of {got.size} channels differ"
+    for k in ("path_samples", "density_lookups", "scatter_events", "ray_queries"):
+        assert st[k] == wst[k], (k, st[k], wst[k])
+    assert st["step_limit_hits"] == 0 and wst["ray_queries"] >= 56 * 48 * 4 and wst["scatter_events"] > 50
+    backend.set_mode(MODE_FAST_LOCAL)
+    fast = backend.render(o, MESH_DELTA)
+    close = np.isclose(fast, want, rtol=1e-4, atol=1e-7).all(axis=2).mean()
+    print(name, "FAST_LOCAL pixels within 1e-4 of the oracle:", close)
+    assert close > 0.97, close
+    # the mesh does bound the medium (the unbounded local tracker gives another frame), and the estimator is the local one:
+    # close to the global-majorant mesh tracker's frame, not equal to it
+    assert not bitexact(backend.render(o, DELTA), fast)
+    backend.set_mode(MODE_FAST)
+    glob = backend.render(o, MESH_DELTA)
+    assert not bitexact(glob, fast) and abs(float(glob.mean()) - float(fast.mean())) < 0.08 * float(glob.mean())
 
 
 def test_mesh_trackers_with_temperature_importance_sampling_crop_and_rotation(backend, oracle):

@@ -617,7 +617,8 @@ int validate(vr_backend* b, const vr_options_pod* o, int integrator)
             return fail(b, VR_ERR_INVALID_ARG, "stepSize min %g is below float resolution at ray parameter %g", o->stepSizeMin, tmax);
         if (std::sqrt(diag) / o->stepSizeMin > 1.0e8f)
             return fail(b, VR_ERR_INVALID_ARG, "stepSize min %g needs more than 1e8 steps across the grid", o->stepSizeMin);
-        if ((b->mode == VR_MODE_FAST_LOCAL || b->mode == VR_MODE_EXACT_LOCAL) && integrator == VR_INTEGRATOR_DELTA_TRACKING) {
+        if ((b->mode == VR_MODE_FAST_LOCAL || b->mode == VR_MODE_EXACT_LOCAL) &&
+            (integrator == VR_INTEGRATOR_DELTA_TRACKING || integrator == VR_INTEGRATOR_MESH_DELTA_TRACKING)) {
             // per-brick majorants change the reference's estimator wherever it scales or clamps its free paths
             if (o->stepSizeMultiplier != 1.0f || o->stepSizeMin > 0.01f || o->stepSizeMax < 1.0e4f)
                 return fail(b, VR_ERR_UNSUPPORTED, "VR_MODE_FAST_LOCAL needs the textbook regime (stepSizeMultiplier 1, stepSizeMin <= 0.01, "
@@ -739,7 +740,8 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
     b->passes_used = 0;
     b->launches = 0;
     const bool exact = b->mode != VR_MODE_FAST && b->mode != VR_MODE_FAST_LOCAL;
-    const bool local_majorants = (b->mode == VR_MODE_FAST_LOCAL || b->mode == VR_MODE_EXACT_LOCAL) && integrator == VR_INTEGRATOR_DELTA_TRACKING;
+    const bool local_majorants = (b->mode == VR_MODE_FAST_LOCAL || b->mode == VR_MODE_EXACT_LOCAL) &&
+                                 (integrator == VR_INTEGRATOR_DELTA_TRACKING || integrator == VR_INTEGRATOR_MESH_DELTA_TRACKING);
     const bool timed = !noalloc;
 
     for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)per_pass) {
@@ -825,9 +827,11 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 // 8 / 16 / 24 / 32 / 44 / 52 / 58 on config 3 textbook; the global-majorant kernels peak at 24)
                 dp.round_max = tuned(b->tune_round_max, 64); dp.round_events = tuned(b->tune_round_events, 44);
                 const bool lds_major = !exact && !b->tune_no_lds_major && (uint64_t)dp.nc[0] * dp.nc[1] * dp.nc[2] <= VR_DDA_LDS_CELLS;
-                void (*dk)(const DdaParams) = exact ? (b->has_temperature ? vr_delta_dda_kernel<true, true> : vr_delta_dda_kernel<false, true>)
-                                            : lds_major ? (b->has_temperature ? vr_delta_dda_kernel<true, false, true> : vr_delta_dda_kernel<false, false, true>)
-                                                        : (b->has_temperature ? vr_delta_dda_kernel<true, false> : vr_delta_dda_kernel<false, false>);
+#define VR_DDA_K(T, E, L) (mesh_bound ? vr_delta_dda_kernel<T, E, L, true> : vr_delta_dda_kernel<T, E, L, false>)
+                void (*dk)(const DdaParams) = exact ? (b->has_temperature ? VR_DDA_K(true, true, false) : VR_DDA_K(false, true, false))
+                                            : lds_major ? (b->has_temperature ? VR_DDA_K(true, false, true) : VR_DDA_K(false, false, true))
+                                                        : (b->has_temperature ? VR_DDA_K(true, false, false) : VR_DDA_K(false, false, false));
+#undef VR_DDA_K
                 int per_cu = 8;
                 rc = launch_cap(b, dk, dp, per_cu);
                 if (rc) return rc;
@@ -875,7 +879,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                                  : (span ? VR_TK5(I, E, S, Q, false, true) : VR_TK5(I, E, S, Q, false, false)))
 #define VR_TRACK_KERNEL(E, S) (ratio ? (is ? VR_TK4(INTEG_RATIO, E, S, true) : VR_TK4(INTEG_RATIO, E, S, false)) \
                                      : (is ? VR_TK4(INTEG_DELTA, E, S, true) : VR_TK4(INTEG_DELTA, E, S, false)))
-            // (only the plain delta tracker has a local-majorant kernel: the LOCAL modes render the other trackers as FAST / EXACT_SKIP)
+            // (only the delta trackers have a local-majorant kernel: the LOCAL modes render the ratio trackers as FAST / EXACT_SKIP)
             const int kmode = b->mode == VR_MODE_FAST_LOCAL ? VR_MODE_FAST : (b->mode == VR_MODE_EXACT_LOCAL ? VR_MODE_EXACT_SKIP : b->mode);
             switch (skip_ok ? kmode : (kmode == VR_MODE_FAST ? -1 : VR_MODE_EXACT)) {
             case -1:                 kern = VR_TRACK_KERNEL(false, false); break;

@@ -1206,8 +1206,11 @@ enum { DD_NEED = 0, DD_WALK = 1, DD_EXHAUSTED = 2, DD_SCATTER = 3, DD_ABSORBED =
 // block copies it into LDS once (16 KB; with the 8 KB of event state six blocks still fit a CU) and the DDA reads a cell's
 // majorant from there instead of from L2 — the walk enters a new cell on two trips out of three and waits for that load.
 #define VR_DDA_LDS_CELLS 4096
-template <bool TEMP, bool EXACT = false, bool LDSMAJ = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT ? 4 : VR_DDA_WAVES, EXACT ? 4 : VR_DDA_WAVES)))
+// MESH (meshDeltaTracking in the LOCAL modes; no reference counterpart, like MESH in vr_track_kernel): every ray of the walk —
+// the primary ray, every scattered ray — is cut to the mesh's entry/exit interval in the event code (mesh_clip), and the lane
+// remembers the object whose medium it is in.  Five waves per SIMD: closest_hit needs registers beside the walk's state.
+template <bool TEMP, bool EXACT = false, bool LDSMAJ = false, bool MESH = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT ? 4 : VR_DDA_WAVES - (MESH ? 1 : 0), EXACT ? 4 : VR_DDA_WAVES - (MESH ? 1 : 0))))
 vr_delta_dda_kernel(const DdaParams p)
 {
     typedef Math<EXACT> M;
@@ -1230,8 +1233,10 @@ vr_delta_dda_kernel(const DdaParams p)
     int32_t  bi = 0, bj = 0, bk = 0;                                  // current brick
     float    mu = 0;                                                  // majorant of the current brick
     uint32_t xs0 = 1, xs1 = 0, xs2 = 0, xs3 = 0;
-    __shared__ float s_ev[8][256];                                    // what only the event code touches
+    __shared__ float s_ev[MESH ? 9 : 8][256];                         // what only the event code touches
     float* const ev = &s_ev[0][threadIdx.x];
+    int&      medium = *(int*)(ev + (MESH ? 8 : 7) * 256);            // MESH: object whose medium the walk is in (else an unused alias)
+    uint32_t  n_queries = 0;
     LdsF3     wdir{ev};                                               // data->rayDirection
     uint32_t& item = *(uint32_t*)(ev + 3 * 256);
     uint32_t& rng_pixel = *(uint32_t*)(ev + 4 * 256);
@@ -1294,7 +1299,13 @@ vr_delta_dda_kernel(const DdaParams p)
                 const f3 point = ray_at(eye, dir, t);                                         // :130
                 wdir = scattered;                                                             // :146
                 float c0 = 1e-5f, c1 = VR_FLT_MAX;
-                if (!ray_clip<EXACT>(point, scattered, c0, c1, c->bmin, c->bmax1)) st = DD_BLACK;   // :150-155 "scattering failed"
+                int  seg = SEG_FOUND;
+                bool seg_empty = false;
+                const bool in_box = ray_clip<EXACT>(point, scattered, c0, c1, c->bmin, c->bmax1);
+                if (MESH && in_box)
+                    seg = mesh_clip(c->mesh, index_to_world(c->mat, c->vec, point), mat_mult(c->mat, scattered), 1.0f, medium, medium, c0, c1,
+                                    seg_empty, n_queries);
+                if (!in_box || (MESH && (seg == SEG_BLACK || seg_empty))) st = DD_BLACK;      // :150-155 "scattering failed"
                 else if (depth_remaining <= 0) st = DD_ESCAPED;                               // :54, :175
                 else { st = DD_WALK; set_ray(point, scattered, c0, c1); }
             }
@@ -1371,7 +1382,16 @@ vr_delta_dda_kernel(const DdaParams p)
                 const float inv_length = M::rcp_(length);
                 const f3 ndir = mk3(inv_length * idir.x, inv_length * idir.y, inv_length * idir.z);
                 float c0 = length * 1e-5f, c1 = VR_FLT_MAX;
-                if (!ray_clip<EXACT>(ieye, ndir, c0, c1, c->bmin, c->bmax1) || c->max_depth == 0) {
+                int  seg = SEG_FOUND;
+                bool seg_empty = false;
+                const bool in_box = ray_clip<EXACT>(ieye, ndir, c0, c1, c->bmin, c->bmax1);
+                if (MESH && in_box) {
+                    medium = -1;
+                    seg = mesh_clip(c->mesh, weye, wd, length, -1, medium, c0, c1, seg_empty, n_queries);
+                }
+                if (MESH && in_box && seg == SEG_BLACK) {
+                    store_sample(p.work.samples, item, mk3(0, 0, 0));                         // an opaque surface
+                } else if (!in_box || c->max_depth == 0 || (MESH && (seg == SEG_NONE || seg_empty))) {
                     store_sample(p.work.samples, item, mk3(c->background[0], c->background[1], c->background[2]));   // :37-39
                 } else {
                     st = DD_WALK;
@@ -1449,7 +1469,9 @@ vr_delta_dda_kernel(const DdaParams p)
     }
 
     unsigned long long a = wave_sum(n_paths), b = wave_sum(n_lookups), c = wave_sum(n_scatter), e = wave_sum(n_limit);
+    const unsigned long long nq = MESH ? wave_sum(n_queries) : 0ull;
     if (lane == 0) {
+        if (MESH) atomicAdd(&p.work.counters->ray_queries, nq);
         atomicAdd(&p.work.counters->path_samples, a);
         atomicAdd(&p.work.counters->density_lookups, b);
         atomicAdd(&p.work.counters->voxel_loads, b);
