@@ -825,7 +825,7 @@ int render_row_set(vr_backend* b, const vr_options_pod* o, int integrator, uint3
                 // a round ends when 44 of the 64 lanes wait for the event code: the phases (path set-up, Philox, direction sample) cost far more
                 // than the DDA steps, so they run as full as they can (swept: 2001 / 2720 / 3218 / 3574 / 3785 / 3765 / 3631 M samples/s for
                 // 8 / 16 / 24 / 32 / 44 / 52 / 58 on config 3 textbook; the global-majorant kernels peak at 24)
-                dp.round_max = tuned(b->tune_round_max, 64); dp.round_events = tuned(b->tune_round_events, 44);
+                dp.round_max = tuned(b->tune_round_max, 64); dp.round_events = tuned(b->tune_round_events, mesh_bound ? 58 : 44);   // (mesh-bounded: the event code holds BVH walks — 1589 / 1485 / 1439 / 1440 ms at 44 / 52 / 58 / 62 on config 5's delta leg)
                 const bool lds_major = !exact && !b->tune_no_lds_major && (uint64_t)dp.nc[0] * dp.nc[1] * dp.nc[2] <= VR_DDA_LDS_CELLS;
 #define VR_DDA_K(T, E, L) (mesh_bound ? vr_delta_dda_kernel<T, E, L, true> : vr_delta_dda_kernel<T, E, L, false>)
                 void (*dk)(const DdaParams) = exact ? (b->has_temperature ? VR_DDA_K(true, true, false) : VR_DDA_K(false, true, false))
