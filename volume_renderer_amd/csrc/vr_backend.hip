@@ -289,7 +289,7 @@ struct vr_backend {
     // developer knobs (VR_TUNE_*), read at the start of each render call; 0 = built-in default
     int  tune_no_geom = 0, tune_no_lds_major = 0;
     bool last_geom = false;          // the last tracking launch took the closed-form voxel runs (GEOM)
-    int tune_tile_h_log = 0, tune_round_max = 0, tune_round_events = 0, tune_chunk = 0, tune_march_tile_h_log = 0, tune_bvh_leaf = 0, tune_major_level = 0;
+    int tune_tile_h_log = 0, tune_round_max = 0, tune_round_events = 0, tune_chunk = 0, tune_march_tile_h_log = 0, tune_bvh_leaf = 0, tune_major_level = 0, tune_bvh_median = 0;
     // hipOccupancyMaxActiveBlocksPerMultiprocessor per kernel, asked once
     struct { const void* kernel; int blocks; } occupancy[64]{};
     int noccupancy = 0;
@@ -455,8 +455,47 @@ struct BuildTri { float lo[3], hi[3], c[3]; uint32_t prim; };
 // against the hit already found.
 struct TreeNode { BvhNode box; int axis; uint32_t left, right; };
 
+// Where to split [first, first + count): the surface-area heuristic over every position along every axis (the triangles sorted by
+// centroid; cost = area(left box) * n_left + area(right box) * n_right), or — `median`, and wherever the heuristic has nothing to
+// choose from — the median along the longest centroid axis.  Leaves `t` sorted along the returned axis.
+uint32_t choose_split(std::vector<BuildTri>& t, uint32_t first, uint32_t count, int longest, bool median, int& axis_out)
+{
+    auto by_axis = [](int axis) { return [axis](const BuildTri& x, const BuildTri& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.prim < y.prim); }; };
+    axis_out = longest;
+    if (median || count < 4) {
+        const uint32_t mid = count / 2;
+        std::nth_element(t.begin() + first, t.begin() + first + mid, t.begin() + first + count, by_axis(longest));
+        return mid;
+    }
+    auto area = [](const float* lo, const float* hi) {
+        const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    double   best = INFINITY;
+    uint32_t best_k = count / 2;
+    int      best_axis = longest;
+    std::vector<double> right(count);
+    for (int axis = 0; axis < 3; ++axis) {
+        std::sort(t.begin() + first, t.begin() + first + count, by_axis(axis));
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (uint32_t i = count; i-- > 1;) {          // right[i] = area of the box of triangles i .. count - 1
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], t[first + i].lo[a]); hi[a] = std::max(hi[a], t[first + i].hi[a]); }
+            right[i] = area(lo, hi);
+        }
+        for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+        for (uint32_t k = 1; k < count; ++k) {        // left = triangles 0 .. k - 1
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], t[first + k - 1].lo[a]); hi[a] = std::max(hi[a], t[first + k - 1].hi[a]); }
+            const double cost = area(lo, hi) * k + right[k] * (count - k);
+            if (cost < best) { best = cost; best_k = k; best_axis = axis; }
+        }
+    }
+    if (best_axis != 2) std::sort(t.begin() + first, t.begin() + first + count, by_axis(best_axis));
+    axis_out = best_axis;
+    return best_k;
+}
+
 uint32_t build_bvh(std::vector<BuildTri>& t, uint32_t first, uint32_t count, std::vector<TreeNode>& tree, std::vector<uint32_t>& order,
-                   uint32_t leaf_size)
+                   uint32_t leaf_size, bool median)
 {
     TreeNode tn{};
     BvhNode& nd = tn.box;
@@ -482,13 +521,12 @@ uint32_t build_bvh(std::vector<BuildTri>& t, uint32_t first, uint32_t count, std
         tree[me].box.leaf = (count << 24) | (uint32_t)order.size();   // (set_mesh checks: < 2^24 triangles, leaves of < 256)
         for (uint32_t i = first; i < first + count; ++i) order.push_back(i);
     } else {
-        const uint32_t mid = count / 2;
-        std::nth_element(t.begin() + first, t.begin() + first + mid, t.begin() + first + count,
-                         [axis](const BuildTri& x, const BuildTri& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.prim < y.prim); });
+        int            split_axis = axis;
+        const uint32_t mid = choose_split(t, first, count, axis, median, split_axis);
         tree[me].box.leaf = 0;
-        tree[me].axis = axis;
-        const uint32_t l = build_bvh(t, first, mid, tree, order, leaf_size);             // lower centroids along `axis`
-        const uint32_t r = build_bvh(t, first + mid, count - mid, tree, order, leaf_size);
+        tree[me].axis = split_axis;
+        const uint32_t l = build_bvh(t, first, mid, tree, order, leaf_size, median);             // lower centroids along the split axis
+        const uint32_t r = build_bvh(t, first + mid, count - mid, tree, order, leaf_size, median);
         tree[me].left = l; tree[me].right = r;
     }
     return me;
@@ -564,7 +602,7 @@ void read_knobs(vr_backend* b)
     b->tune_march_tile_h_log = plus1("VR_TUNE_MARCH_TILE_H_LOG");
     b->tune_major_level = plus1("VR_TUNE_MAJORANT_LEVEL");
     b->tune_round_max = tune_env("VR_TUNE_ROUND_MAX"); b->tune_round_events = tune_env("VR_TUNE_ROUND_EVENTS");
-    b->tune_chunk = tune_env("VR_TUNE_CHUNK"); b->tune_bvh_leaf = tune_env("VR_TUNE_BVH_LEAF");
+    b->tune_chunk = tune_env("VR_TUNE_CHUNK"); b->tune_bvh_leaf = tune_env("VR_TUNE_BVH_LEAF"); b->tune_bvh_median = tune_env("VR_TUNE_BVH_MEDIAN");
     b->tune_no_geom = tune_env("VR_TUNE_NO_GEOM"); b->tune_no_lds_major = tune_env("VR_TUNE_NO_LDS_MAJOR");
 }
 
@@ -1178,7 +1216,7 @@ int vr_backend_set_mesh(vr_backend* b, const vr_mesh_desc* m)
     std::vector<uint32_t> order;
     read_knobs(b);
     if (m->ntris >= (1u << 24)) return fail(b, VR_ERR_INVALID_ARG, "%u triangles: a BVH leaf addresses 2^24", m->ntris);
-    build_bvh(bt, 0, m->ntris, tree, order, (uint32_t)std::min(b->tune_bvh_leaf > 0 ? b->tune_bvh_leaf : 1, 255));
+    build_bvh(bt, 0, m->ntris, tree, order, (uint32_t)std::min(b->tune_bvh_leaf > 0 ? b->tune_bvh_leaf : 1, 255), b->tune_bvh_median != 0);
     std::vector<BvhNode>  nodes;                         // 8 layouts of tree.size() nodes each
     for (int octant = 0; octant < 8; ++octant) thread_bvh(tree, 0, octant, nodes, nodes.size());
     std::vector<TriDev> tris(order.size());
