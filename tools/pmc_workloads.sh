@@ -8,7 +8,7 @@ O=$R/gpurun_out/pmc_wl
 [ -z "$ENTRIES" ] && rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # ENTRIES="workload mode;workload mode" overrides the list (and keeps the files of earlier runs)
-DEFAULT="config2_textbook fast;config3_delta_1080p_256spp_cloud512 fast;config3_textbook fast;config3_textbook local;config4_delta_4k_256spp_cloud1024 fast;config4_delta_4k_256spp_cloud1024 local;config5_tracker_ratio_sphere_4k fast;config5_tracker_delta_sphere_4k fast;config5_tracker_delta_shipped_sphere_4k fast;gridmarch_simple_1080p_cloud512 fast;config1_marcher_cube_512_1spp fast;config5_marcher_sphere_4k fast;config5_marcher_nee_sphere_4k fast;config5_marcher_cornell_4k fast;config5_marcher_nee_cornell_4k fast;perlin_marcher_sphere_1080p fast;small fast"
+DEFAULT="config2_textbook fast;config3_delta_1080p_256spp_cloud512 fast;config3_textbook fast;config3_textbook local;config4_delta_4k_256spp_cloud1024 fast;config4_delta_4k_256spp_cloud1024 local;config5_tracker_ratio_sphere_4k fast;config5_tracker_delta_sphere_4k fast;config5_tracker_delta_sphere_4k local;config5_tracker_delta_shipped_sphere_4k fast;gridmarch_simple_1080p_cloud512 fast;config1_marcher_cube_512_1spp fast;config5_marcher_sphere_4k fast;config5_marcher_nee_sphere_4k fast;config5_marcher_cornell_4k fast;config5_marcher_nee_cornell_4k fast;perlin_marcher_sphere_1080p fast;small fast"
 IFS=';' read -ra LIST <<< "${ENTRIES:-$DEFAULT}"
 for e in "${LIST[@]}"; do
   set -- $e

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_wl
 [ -z "$ONLY" ] && rm -rf $O; mkdir -p $O     # ONLY="workload mode;workload mode": just those entries, keeping the others' files
 cd /tmp && export TMPDIR=/tmp
-for e in "config3_delta_1080p_256spp_cloud512 fast" "config3_textbook fast" "config3_textbook local" "config2_textbook fast" \
+for e in "config3_delta_1080p_256spp_cloud512 fast" "config3_textbook fast" "config3_textbook local" "config5_tracker_delta_sphere_4k local" "config2_textbook fast" \
          "config4_delta_4k_256spp_cloud1024 fast" "config4_delta_4k_256spp_cloud1024 local" "config1_marcher_cube_512_1spp fast" \
          "config5_marcher_sphere_4k fast" "config5_marcher_nee_sphere_4k fast" "config5_marcher_cornell_4k fast" "config5_marcher_nee_cornell_4k fast" "config5_tracker_ratio_sphere_4k fast" \
          "config5_tracker_delta_sphere_4k fast" "config5_tracker_delta_shipped_sphere_4k fast" "gridmarch_simple_1080p_cloud512 fast" \

@@ -1206,11 +1206,15 @@ enum { DD_NEED = 0, DD_WALK = 1, DD_EXHAUSTED = 2, DD_SCATTER = 3, DD_ABSORBED =
 // block copies it into LDS once (16 KB; with the 8 KB of event state six blocks still fit a CU) and the DDA reads a cell's
 // majorant from there instead of from L2 — the walk enters a new cell on two trips out of three and waits for that load.
 #define VR_DDA_LDS_CELLS 4096
+#ifndef VR_DDA_MESH_WAVES_LESS
+#define VR_DDA_MESH_WAVES_LESS 2   // the mesh-bounded build gets this many waves per SIMD fewer: at four (128 VGPRs) closest_hit runs without the 192 bytes of
+                                   // scratch it spilled at five — config 5's delta leg 1342 -> 1102 ms; three waves: 1181
+#endif
 // MESH (meshDeltaTracking in the LOCAL modes; no reference counterpart, like MESH in vr_track_kernel): every ray of the walk —
 // the primary ray, every scattered ray — is cut to the mesh's entry/exit interval in the event code (mesh_clip), and the lane
-// remembers the object whose medium it is in.  Five waves per SIMD: closest_hit needs registers beside the walk's state.
+// remembers the object whose medium it is in.  Four waves per SIMD: closest_hit needs registers beside the walk's state.
 template <bool TEMP, bool EXACT = false, bool LDSMAJ = false, bool MESH = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT ? 4 : VR_DDA_WAVES - (MESH ? 1 : 0), EXACT ? 4 : VR_DDA_WAVES - (MESH ? 1 : 0))))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT ? 4 : VR_DDA_WAVES - (MESH ? VR_DDA_MESH_WAVES_LESS : 0), EXACT ? 4 : VR_DDA_WAVES - (MESH ? VR_DDA_MESH_WAVES_LESS : 0))))
 vr_delta_dda_kernel(const DdaParams p)
 {
     typedef Math<EXACT> M;
