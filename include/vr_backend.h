@@ -36,7 +36,7 @@ enum {
     /* EXACT arithmetic with FAST's batched empty-space stepping: must also be bit-identical to
      * the oracle; exists so that tests can pin the batching on its own. */
     VR_MODE_EXACT_SKIP = 2,
-    /* FAST, and deltaTracking sampled against PER-BRICK majorants (a coarse majorant grid walked by a 3-D DDA)
+    /* FAST, and deltaTracking (and meshDeltaTracking) sampled against PER-CELL majorants (a coarse majorant grid walked by a 3-D DDA)
      * instead of the reference's single global one (IntegratorDeltaTracking.cpp:44-47).  Opt-in, and NOT the
      * reference's estimator: it is textbook delta tracking (the density is looked up at the tentative collision,
      * not one free path earlier), offered only where the reference's own parameters make it a plain delta
