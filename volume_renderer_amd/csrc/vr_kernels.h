@@ -368,6 +368,16 @@ enum {
 #ifndef VR_ONE_STREAM_EXP
 #define VR_ONE_STREAM_EXP 0   // timing experiment: FAST walks go on drawing from the path's first stream (no Philox per walk)
 #endif
+// Wave priorities (s_setprio): a wave in the step loop is preferred by its SIMD's issue arbiter over a wave in the event phase, which
+// serves a dozen lanes with long dependent chains (Philox, reciprocals, the lookup of a new ray) and fills the slots the walkers leave.
+// Measured with 3 / 0 against no priorities: config 2 643.6 -> 634.2 ms (+1.5 %), config 3 as shipped +0.9 %, config 2 textbook +0.8 %,
+// config 4 and the mesh-bounded kernels +-0.3 %; the reverse (event phase first) 0 to -1 %.  VR_EVENT_PRIO -1 = none.
+#ifndef VR_EVENT_PRIO
+#define VR_EVENT_PRIO 0
+#endif
+#ifndef VR_STEP_PRIO
+#define VR_STEP_PRIO 3
+#endif
 #define VR_ROUND_MAX 48      // step-loop trips before the event phase runs regardless
 #define VR_ROUND_EVENTS 12   // ... or as soon as this many lanes wait for it
 // Iterations of the reference's loop per trip.  A trip ends with ONE empty-space service and ONE voxel
@@ -587,6 +597,9 @@ vr_track_kernel(const TrackParams p)
     for (;;) {
         // =========================== event phase ===========================
         w_phases++;
+#if VR_EVENT_PRIO >= 0
+        __builtin_amdgcn_s_setprio(VR_EVENT_PRIO);
+#endif
         // (-1) FLAT iterations: real collisions of the camera walk, left undecided by the step loop.  The lane kept the event
         // word in cur_off and the step's length in t_span (both dead for a walk that has collided: its next ray resets them).
         if (FLAT && __any(st == ST_COLLIDED)) {
@@ -851,6 +864,9 @@ vr_track_kernel(const TrackParams p)
         // the iterations: a lane that finds sigma <= 0 sits out the rest of the trip and takes its
         // run there.
         if (st == ST_WALK && rng_step > p.work.step_limit) { n_limit++; st = ST_FINISHED; }   // safety cap, once per round
+#if VR_EVENT_PRIO >= 0
+        __builtin_amdgcn_s_setprio(VR_STEP_PRIO);
+#endif
 #pragma unroll 1
         for (int it = 0; it < p.round_max; ++it) {
           if constexpr (GEOM) {
