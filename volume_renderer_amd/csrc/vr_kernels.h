@@ -371,12 +371,18 @@ enum {
 // Wave priorities (s_setprio): a wave in the step loop is preferred by its SIMD's issue arbiter over a wave in the event phase, which
 // serves a dozen lanes with long dependent chains (Philox, reciprocals, the lookup of a new ray) and fills the slots the walkers leave.
 // Measured with 3 / 0 against no priorities: config 2 643.6 -> 634.2 ms (+1.5 %), config 3 as shipped +0.9 %, config 2 textbook +0.8 %,
-// config 4 and the mesh-bounded kernels +-0.3 %; the reverse (event phase first) 0 to -1 %.  VR_EVENT_PRIO -1 = none.
+// the reverse (event phase first) 0 to -1 %.  VR_EVENT_PRIO -1 = none.
 #ifndef VR_EVENT_PRIO
 #define VR_EVENT_PRIO 0
 #endif
 #ifndef VR_STEP_PRIO
 #define VR_STEP_PRIO 3
+#endif
+// ... and within a trip the iterations (44 of 64 lanes busy) go before the empty-space and lookup blocks (10 and 22 lanes): another
+// +0.7 % on config 2.  Only the kernels with sub-voxel steps (SPAN) set priorities: with voxel-sized steps (one iteration per trip,
+// a lookup in every one) the same settings cost config 3 textbook 0.8 % + 0.9 %.
+#ifndef VR_SERVICE_PRIO
+#define VR_SERVICE_PRIO 1
 #endif
 #define VR_ROUND_MAX 48      // step-loop trips before the event phase runs regardless
 #define VR_ROUND_EVENTS 12   // ... or as soon as this many lanes wait for it
@@ -598,7 +604,7 @@ vr_track_kernel(const TrackParams p)
         // =========================== event phase ===========================
         w_phases++;
 #if VR_EVENT_PRIO >= 0
-        __builtin_amdgcn_s_setprio(VR_EVENT_PRIO);
+        if (SPAN) __builtin_amdgcn_s_setprio(VR_EVENT_PRIO);
 #endif
         // (-1) FLAT iterations: real collisions of the camera walk, left undecided by the step loop.  The lane kept the event
         // word in cur_off and the step's length in t_span (both dead for a walk that has collided: its next ray resets them).
@@ -865,7 +871,7 @@ vr_track_kernel(const TrackParams p)
         // run there.
         if (st == ST_WALK && rng_step > p.work.step_limit) { n_limit++; st = ST_FINISHED; }   // safety cap, once per round
 #if VR_EVENT_PRIO >= 0
-        __builtin_amdgcn_s_setprio(VR_STEP_PRIO);
+        if (SPAN) __builtin_amdgcn_s_setprio(VR_STEP_PRIO);
 #endif
 #pragma unroll 1
         for (int it = 0; it < p.round_max; ++it) {
@@ -932,6 +938,9 @@ vr_track_kernel(const TrackParams p)
             const int n_event = __popcll(__ballot(st >= ST_SCATTER));
             if (n_event >= p.round_events || n_walk == 0) break;
           } else {
+#if VR_SERVICE_PRIO >= 0
+            if (SPAN) __builtin_amdgcn_s_setprio(VR_STEP_PRIO);
+#endif
             bool empty = false;     // this lane's current iteration is an empty-space step, still to be taken
             bool parked = false;    // this lane has left its voxel and waits for the lookup at the end of the trip
 #pragma unroll
@@ -1117,6 +1126,9 @@ vr_track_kernel(const TrackParams p)
                     }
                 }
             }
+#if VR_SERVICE_PRIO >= 0
+            if (SPAN) __builtin_amdgcn_s_setprio(VR_SERVICE_PRIO);
+#endif
             // empty-space steps: tFar += constant, no draw                                   :84-96 / :251-263 (delta :70-82)
             if (empty) {
                 const bool  in_shadow = (INTEG == INTEG_RATIO) && shadow;
