@@ -103,8 +103,10 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None):
-    """Oracle (port of the reference algorithm) on the host cores, bounded sample of the same frame."""
+def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None, gpu_frame=None):
+    """Oracle (port of the reference algorithm) on the host cores, bounded sample of the same frame.  With the GPU's frame at
+    hand the sample doubles as a full-size cross-check: the oracle's rows (one sub-sample per pixel, the reference's own
+    generator) against the same rows of the frame the timed steps rendered."""
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
 
@@ -133,10 +135,12 @@ def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None):
         scene, _keep = ol.make_scene(density=grid, mesh=mesh)
     o1 = copy_options(opts, rayPerPixelCount=1)   # 1 sub-sample per pixel, scaled linearly in spp
 
+    got = {}
+
     def rows(row_list):
         def one(j):
             t = time.perf_counter()
-            ol.render_rows(scene, o1, integ_id, j, j + 1, rng_mode=ol.RNG_REFERENCE)
+            got[j] = ol.render_rows(scene, o1, integ_id, j, j + 1, rng_mode=ol.RNG_REFERENCE)[0][0]
             return time.perf_counter() - t
         t0 = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:
@@ -153,7 +157,19 @@ def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None):
     sample = list(range(stride // 2, H, stride))
     ts = rows(sample)
     samples = len(sample) * W
+    check = None
+    if gpu_frame is not None:
+        js = sorted(got)
+        cpu = np.stack([got[j] for j in js]).astype(np.float64)              # (rows, W, 3), 1 sub-sample per pixel
+        gpu = np.asarray(gpu_frame, dtype=np.float64)[js]                    # the same rows at the frame's sample count
+        d = (cpu - gpu).mean(axis=2).ravel()
+        se = d.std(ddof=1) / np.sqrt(d.size)
+        check = {"rows": len(js), "oracle_mean": float(cpu.mean()), "gpu_mean": float(gpu.mean()),
+                 "rel_diff": float((cpu.mean() - gpu.mean()) / max(abs(gpu.mean()), 1e-30)), "z": float(d.mean() / max(se, 1e-30)),
+                 "what": "mean radiance over the sampled rows: oracle (reference scheme, 1 sub-sample per pixel) against the frame the "
+                         "timed steps rendered; z = mean difference over its standard error across pixels"}
     return {
+        "cross_check": check,
         "value": samples / ts / 1e6,
         "unit": "Mpath-samples/s",
         "cores": cores,
@@ -519,7 +535,8 @@ def main():
         want_cpu = a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and world == 1)
         if want_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(integ_id, n, opts, a.cpu_seconds, mesh)
+                out["cpu_baseline"] = cpu_baseline(integ_id, n, opts, a.cpu_seconds, mesh,
+                                                   gpu_frame=sched.frame.cpu().numpy() if world == 1 and weak is None else None)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mpath-samples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
