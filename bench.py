@@ -103,10 +103,12 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None, gpu_frame=None):
+def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None, gpu_frame=None, local=False):
     """Oracle (port of the reference algorithm) on the host cores, bounded sample of the same frame.  With the GPU's frame at
     hand the sample doubles as a full-size cross-check: the oracle's rows (one sub-sample per pixel, the reference's own
-    generator) against the same rows of the frame the timed steps rendered."""
+    generator) against the same rows of the frame the timed steps rendered.  The local-majorant modes are not the reference's estimator
+    (+1 % image mean on the 512^3 cloud); their frames are checked against the oracle's restatement of THAT tracker,
+    rendered over the same rows after the timed sample (the baseline's value stays the reference algorithm's)."""
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
 
@@ -159,6 +161,17 @@ def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None, gpu_frame=None):
     samples = len(sample) * W
     check = None
     if gpu_frame is not None:
+        which = "reference scheme"
+        if local:
+            ol.local_majorants(scene)
+            local_id = ol.MESH_DELTA_LOCAL if (mesh is not None and isinstance(n, int)) else ol.DELTA_LOCAL
+            which = "local-majorant tracker, reference generator"
+
+            def one_local(j):
+                got[j] = ol.render_rows(scene, o1, local_id, j, j + 1, rng_mode=ol.RNG_REFERENCE)[0][0]
+            with ThreadPoolExecutor(cores) as ex:
+                list(ex.map(one_local, sorted(got)))
+            L.vro_local_majorants_free()
         js = sorted(got)
         cpu = np.stack([got[j] for j in js]).astype(np.float64)              # (rows, W, 3), 1 sub-sample per pixel
         gpu = np.asarray(gpu_frame, dtype=np.float64)[js]                    # the same rows at the frame's sample count
@@ -166,7 +179,7 @@ def cpu_baseline(integ_id, n, opts, target_seconds, mesh=None, gpu_frame=None):
         se = d.std(ddof=1) / np.sqrt(d.size)
         check = {"rows": len(js), "oracle_mean": float(cpu.mean()), "gpu_mean": float(gpu.mean()),
                  "rel_diff": float((cpu.mean() - gpu.mean()) / max(abs(gpu.mean()), 1e-30)), "z": float(d.mean() / max(se, 1e-30)),
-                 "what": "mean radiance over the sampled rows: oracle (reference scheme, 1 sub-sample per pixel) against the frame the "
+                 "what": f"mean radiance over the sampled rows: oracle ({which}, 1 sub-sample per pixel) against the frame the "
                          "timed steps rendered; z = mean difference over its standard error across pixels"}
     return {
         "cross_check": check,
@@ -536,7 +549,8 @@ def main():
         if want_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(integ_id, n, opts, a.cpu_seconds, mesh,
-                                                   gpu_frame=sched.frame.cpu().numpy() if world == 1 and weak is None else None)
+                                                   gpu_frame=sched.frame.cpu().numpy() if world == 1 and weak is None else None,
+                                                   local=a.mode == "local")
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mpath-samples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
