@@ -33,7 +33,9 @@ Prints ONE JSON line on rank 0 (contract in the task description) with two extra
                 that issued a load, `hbm` = traffic from the committed PMC passes (= `traffic`), `valu` = instruction rate,
                 lane utilisation, scalar instructions, share of wave cycles waiting (profiles/pmc_traffic.json)
   cpu_baseline  the CPU oracle (a port of the reference algorithm) on the host cores, on a
-                bounded sample of the same frame (N=1 only)
+                bounded sample of the same frame (N=1 only).  Its `cross_check` compares the sample's rows (one sub-sample
+                per pixel, the reference's own generator) with the same rows of the frame the timed steps rendered: image
+                means, relative difference and z = mean difference over its standard error across pixels
 
 --client group (single process, no torch.distributed): the frame over GPUs 0..N-1 through vr_group_render, the client
 behind the C-ABI that INTEGRATION.md 6 recommends (BaseIntegrator.cpp:143-181 replaced in one call); VR_BENCH_GROUP_DEVICES
